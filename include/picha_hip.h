@@ -1,0 +1,178 @@
+/*
+ * picha_hip.h — C ABI of libpicha_hip.so: the MI355X (gfx950) implementation of picha's
+ * pixel hot path (separable filtered resize + pixel-format / colour conversion).
+ *
+ * This is the drop-in boundary.  Every entry point below is what the reference's native
+ * addon would bind for this path; the reference interface each one replaces is cited as
+ * file:line into jhs67/picha v0.5.7.  Plain C: no C++ types, no exceptions, no torch types.
+ * All functions return 0 (PICHA_OK) or a negative picha_status; the message of the last
+ * failure on the calling thread is available from picha_hip_last_error().
+ *
+ * There is NO CPU fallback behind these entry points: if no gfx950 device is usable the
+ * compute calls fail with PICHA_ERR_NO_DEVICE / PICHA_ERR_HIP.
+ */
+#ifndef PICHA_HIP_H_
+#define PICHA_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Pixel formats; values are the reference's PixelMode enum (src/picha.h:79-92). */
+enum picha_pixel {
+    PICHA_INVALID_PIXEL = -1,
+    PICHA_RGB = 0,          /* 3 x u8  */
+    PICHA_RGBA = 1,         /* 4 x u8  */
+    PICHA_GREY = 2,         /* 1 x u8  */
+    PICHA_GREYA = 3,        /* 2 x u8  */
+    PICHA_R16 = 4,          /* 1 x u16 (native endian) */
+    PICHA_R16G16 = 5,       /* 2 x u16 */
+    PICHA_R16G16B16 = 6,    /* 3 x u16 */
+    PICHA_R16G16B16A16 = 7, /* 4 x u16 */
+    PICHA_NUM_PIXELS = 8
+};
+
+/* Resize filters; values are the reference's ResizeFilterTag (src/resize.cc:151-160). */
+enum picha_filter {
+    PICHA_FILTER_CUBIC = 0,
+    PICHA_FILTER_LANCZOS = 1,
+    PICHA_FILTER_CATMULROM = 2,
+    PICHA_FILTER_MITCHEL = 3,
+    PICHA_FILTER_BOX = 4,
+    PICHA_FILTER_TRIANGLE = 5,
+    PICHA_NUM_FILTERS = 6
+};
+
+enum picha_status {
+    PICHA_OK = 0,
+    PICHA_ERR_INVALID_IMAGE = -1,      /* "invalid image"        (src/resize.cc:336-339, src/picha.cc:61-85) */
+    PICHA_ERR_INVALID_DIMENSIONS = -2, /* "invalid dimensions"   (src/resize.cc:343-346) */
+    PICHA_ERR_INVALID_FILTER = -3,     /* "invalid filter mode"  (src/resize.cc:184-187) */
+    PICHA_ERR_INVALID_FILTER_WIDTH = -4, /* "invalid filter width" (src/resize.cc:192-195) */
+    PICHA_ERR_PIXEL_MISMATCH = -5,     /* assert(src.pixel == dst.pixel) (src/resize.cc:137); size asserts (src/colorconvert.cc:138-139) */
+    PICHA_ERR_EXPECTED_PIXEL = -6,     /* "expected pixel mode"  (src/colorconvert.cc:236-239) */
+    PICHA_ERR_DEGENERATE_TAPS = -7,    /* assert(totalweight > 0) (src/resize.cc:45) — the reference aborts */
+    PICHA_ERR_NO_DEVICE = -8,          /* no usable gfx950 device */
+    PICHA_ERR_HIP = -9,                /* HIP runtime failure; text in picha_hip_last_error() */
+    PICHA_ERR_ARGUMENT = -10           /* null pointer / negative count at the C boundary */
+};
+
+/*
+ * Image descriptor; mirrors NativeImage {data, stride, width, height, pixel}
+ * (src/picha.h:202-218).  row(y) = data + y * stride.  `data` is a host pointer for the
+ * host entry points and a device pointer for the *_device entry points.
+ */
+typedef struct picha_image {
+    void *data;
+    int32_t stride;
+    int32_t width;
+    int32_t height;
+    int32_t pixel; /* enum picha_pixel */
+} picha_image;
+
+/* ---- format helpers (src/picha.h:174-200, 212-215) -------------------------------------- */
+int picha_pixel_bytes(int pixel);    /* pixelBytes();   0 for an invalid format */
+int picha_pixel_channels(int pixel); /* pixelChannels(); 0 for an invalid format */
+int picha_row_stride(int width, int pixel); /* NativeImage::row_stride: (bytes*w + 3) & ~3 */
+/* pixelSymbolToEnum / pixelEnumToSymbol (src/picha.cc:36-51): "rgb", "rgba", ... */
+int picha_pixel_from_name(const char *name); /* PICHA_INVALID_PIXEL if unknown */
+const char *picha_pixel_name(int pixel);     /* NULL if invalid */
+/* symbolToResizeFilter (src/resize.cc:162-171): "cubic","lanczos","catmulrom","mitchel","box","triangle" */
+int picha_filter_from_name(const char *name); /* -1 if unknown */
+const char *picha_filter_name(int filter);
+
+/* ---- option marshalling -------------------------------------------------------------------- */
+/*
+ * getResizeOptions (src/resize.cc:173-198).  Defaults {cubic, 0.70f}; if has_filter the scale
+ * resets to 1.0f and `filter` must be valid (else PICHA_ERR_INVALID_FILTER); if has_filter_scale
+ * the scale is float(filter_scale) and NaN or <= 0 gives PICHA_ERR_INVALID_FILTER_WIDTH.
+ */
+int picha_resize_options(int has_filter, int filter, int has_filter_scale, double filter_scale,
+                         int *out_filter, float *out_scale);
+/*
+ * ColorSettings + getSettings (src/colorconvert.h:11-14, src/colorconvert.cc:6-22).  Pass NaN for
+ * a weight the caller did not supply.  out[3] = normalised {r, g, b} factors.
+ */
+void picha_color_settings(double red_weight, double green_weight, double blue_weight, float out[3]);
+
+/*
+ * makeContribs (src/resize.cc:19-50) for ScaledFilter<filter>(filter_scale) mapping src_size
+ * samples onto dst_size.  Exposed so tests can compare the product's host tap builder with the
+ * oracle.  left/right: dst_size ints each.  weights: dst_size * max_taps floats, row i holds the
+ * taps of output i (zero padded).  *taps_out receives the largest tap count.  Returns
+ * PICHA_ERR_ARGUMENT if max_taps is too small (then *taps_out tells the size needed).
+ */
+int picha_hip_make_contribs(int filter, float filter_scale, int src_size, int dst_size,
+                            int32_t *left, int32_t *right, float *weights, int max_taps,
+                            int *taps_out);
+
+/* ---- runtime ------------------------------------------------------------------------------- */
+const char *picha_hip_last_error(void); /* thread-local text of the last failure ("" if none) */
+const char *picha_hip_strerror(int status); /* the reference's message string for a status */
+int picha_hip_device_count(void); /* number of visible HIP devices (0 if none / no driver) */
+/* Name of the gcnArch of the current device into buf (e.g. "gfx950"). */
+int picha_hip_device_arch(char *buf, size_t len);
+/*
+ * Tuning / test knobs (outside the drop-in surface).  Keys:
+ *   "path"      0 = auto, 1 = force the two-pass scratch kernels, 2 = force the fused kernel
+ *   "row_chunks" 0 = auto, else number of row chunks per image for the fused kernel
+ * Returns PICHA_ERR_ARGUMENT for an unknown key.
+ */
+int picha_hip_set_option(const char *key, long value);
+long picha_hip_get_option(const char *key);
+/* Name of the kernel family the last resize on this thread used ("fused<...>" / "twopass"). */
+const char *picha_hip_last_kernel(void);
+
+/* ---- the hot path: host-pointer entry points -------------------------------------------------
+ * These replace the two functions the reference's NAN methods and libuv workers call:
+ *   resizeImage(const ResizeOptions&, NativeImage& src, NativeImage& dst)   src/resize.cc:270-280
+ *     (called from UV_resize src/resize.cc:291-294 and NAN_METHOD(resizeSync) src/resize.cc:399)
+ *   doColorConvert(const ColorSettings&, NativeImage& src, NativeImage& dst) src/colorconvert.cc:171-188
+ *     (called from UV_colorConvert src/colorconvert.cc:199-202 and colorConvertSync :288)
+ * `data` pointers are host memory; the call uploads, runs the HIP kernels on the current device,
+ * downloads into dst->data and returns when dst is complete.  dst row padding is left untouched
+ * (the reference never writes it either, src/resize.cc:122-132).  Thread-safe.
+ */
+int picha_hip_resize(const picha_image *src, const picha_image *dst, int filter, float filter_scale);
+int picha_hip_color_convert(const picha_image *src, const picha_image *dst,
+                            float r_factor, float g_factor, float b_factor);
+/* n independent images in one call (one H2D / kernel / D2H pipeline); same semantics per image. */
+int picha_hip_resize_batch(int n, const picha_image *src, const picha_image *dst, int filter,
+                           float filter_scale);
+int picha_hip_color_convert_batch(int n, const picha_image *src, const picha_image *dst,
+                                  float r_factor, float g_factor, float b_factor);
+
+/* ---- the hot path: device-resident entry points ------------------------------------------------
+ * Same operations on images whose `data` already lives in the current device's HBM.  Asynchronous:
+ * work is enqueued on `stream` (a hipStream_t passed as void*, NULL = the default stream) and the
+ * call returns; no allocation or synchronisation happens once the tap tables for the geometry are
+ * cached (first call for a geometry builds and uploads them).  Images of one call may differ in
+ * geometry; equal-geometry runs are grouped into single launches.
+ */
+int picha_hip_resize_device(int n, const picha_image *src, const picha_image *dst, int filter,
+                            float filter_scale, void *stream);
+int picha_hip_color_convert_device(int n, const picha_image *src, const picha_image *dst,
+                                   float r_factor, float g_factor, float b_factor, void *stream);
+
+/* ---- device memory helpers for hosts without an allocator of their own (Node addon, C tests) --- */
+int picha_hip_malloc(void **dev_ptr, size_t bytes);
+int picha_hip_free(void *dev_ptr);
+int picha_hip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream);
+int picha_hip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
+int picha_hip_stream_synchronize(void *stream);
+/*
+ * Synthetic pixels: sample k of the buffer = top bits of
+ * splitmix64(seed ^ k) as u8 (sample_bytes 1) or little-endian u16 (sample_bytes 2).
+ */
+int picha_hip_fill_random(void *dev_ptr, size_t bytes, uint64_t seed, int sample_bytes, void *stream);
+/* Host twin of the generator (same values), for parity checks on sub-batches. */
+void picha_fill_random_host(void *host_ptr, size_t bytes, uint64_t seed, int sample_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* PICHA_HIP_H_ */

@@ -1,0 +1,230 @@
+"""Host-side mirror of picha's operator API for the pixel hot path.
+
+    resize(image, opts, cb) / resizeSync(image, opts)              reference index.js:13-21, src/resize.cc:321-403
+    colorConvert(image, opts, cb) / colorConvertSync(image, opts)  reference index.js:25-33, src/colorconvert.cc:215-291
+
+Same option names and semantics, same error strings; results are `Image` objects.  The async
+variants run the C-ABI call on a worker pool and deliver `cb(None, image)` (the reference's
+callbacks likewise never receive an error for argument problems — those throw synchronously,
+SURVEY.md quirk 7; a device failure, a class of error the reference does not have, is delivered
+as cb(err, None)).
+"""
+import concurrent.futures
+import ctypes
+import math
+import numbers
+
+import numpy as np
+
+from . import _native as N
+from .image import Image
+
+PichaError = N.PichaError
+
+_pool = None
+
+
+def _executor():
+    global _pool
+    if _pool is None:
+        # the reference dispatches to libuv's pool, default 4 threads (src/resize.cc:362-364)
+        _pool = concurrent.futures.ThreadPoolExecutor(max_workers=4, thread_name_prefix="picha")
+    return _pool
+
+
+def _get(obj, key):
+    if isinstance(obj, dict):
+        return obj.get(key)
+    return getattr(obj, key, None)
+
+
+def _uint32(v):
+    """JS ToUint32 of a property (undefined / NaN -> 0)."""
+    if v is None or not isinstance(v, numbers.Real):
+        return 0
+    if isinstance(v, float) and (math.isnan(v) or math.isinf(v)):
+        return 0
+    return int(v) & 0xFFFFFFFF
+
+
+def _to_int32(u):
+    """Uint32Value stored into a C int (src/resize.cc:341-342): values > 2^31-1 wrap negative."""
+    return u - (1 << 32) if u >= (1 << 31) else u
+
+
+def _native_image(img):
+    """jsImageToNativeImage (src/picha.cc:61-85).  Returns (CImage, keepalive) or None if invalid."""
+    if img is None or isinstance(img, (int, float, str, bytes)):
+        return None
+    width = _to_int32(_uint32(_get(img, "width")))
+    height = _to_int32(_uint32(_get(img, "height")))
+    stride = _to_int32(_uint32(_get(img, "stride")))
+    pixel = N.pixel_index(_get(img, "pixel")) if isinstance(_get(img, "pixel"), str) else -1
+    data = _get(img, "data")
+    if pixel < 0 or data is None:
+        return None
+    if not isinstance(data, np.ndarray):
+        try:
+            data = np.frombuffer(data, dtype=np.uint8)
+        except (TypeError, ValueError):
+            return None
+    if data.dtype != np.uint8 or data.ndim != 1 or not data.flags["C_CONTIGUOUS"]:
+        return None
+    rw = N.PIXEL_BYTES[N.PIXELS[pixel]] * width
+    if not (data.size >= height * stride - stride + rw and height != 0):
+        return None
+    if width <= 0 or height < 0 or stride < 0:
+        return None
+    return N.CImage(data.ctypes.data, stride, width, height, pixel), data
+
+
+def _new_image(width, height, pixel):
+    """newJsImage (src/picha.cc:119-133): stride = row_stride, data uninitialised."""
+    stride = (N.PIXEL_BYTES[pixel] * width + 3) & ~3
+    data = np.empty(height * stride, dtype=np.uint8)
+    return Image(width=width, height=height, pixel=pixel, stride=stride, data=data)
+
+
+def _resize_options(opts):
+    """getResizeOptions (src/resize.cc:179-198)."""
+    L = N.lib()
+    f = _get(opts, "filter")
+    has_filter = f is not None
+    tag = -1
+    if has_filter:
+        tag = L.picha_filter_from_name(f.encode()) if isinstance(f, str) else -1
+    fs = _get(opts, "filterScale")
+    has_scale = fs is not None
+    scale = float("nan")
+    if has_scale:
+        try:
+            scale = float(fs)
+        except (TypeError, ValueError):
+            scale = float("nan")
+    out_f, out_s = ctypes.c_int(), ctypes.c_float()
+    N.check(L.picha_resize_options(int(has_filter), tag, int(has_scale), scale, ctypes.byref(out_f), ctypes.byref(out_s)))
+    return out_f.value, out_s.value
+
+
+def _prepare_resize(image, opts, expected):
+    if not _is_object(image) or not _is_object(opts):
+        raise PichaError(expected)
+    src = _native_image(image)
+    if src is None:
+        raise PichaError("invalid image")
+    width = _to_int32(_uint32(_get(opts, "width")))
+    height = _to_int32(_uint32(_get(opts, "height")))
+    if width <= 0 or height <= 0:
+        raise PichaError("invalid dimensions")
+    ftag, fscale = _resize_options(opts)
+    dst = _new_image(width, height, N.PIXELS[src[0].pixel])
+    return src, dst, ftag, fscale
+
+
+def _is_object(o):
+    return o is not None and not isinstance(o, (int, float, str, bytes, bool))
+
+
+def _run_resize(src, dst, ftag, fscale):
+    cdst = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index(dst.pixel))
+    N.check(N.lib().picha_hip_resize(ctypes.byref(src[0]), ctypes.byref(cdst), ftag, fscale))
+    return dst
+
+
+def resizeSync(image, opts):
+    src, dst, ftag, fscale = _prepare_resize(image, opts, "expected: resizeSync(image, opts)")
+    return _run_resize(src, dst, ftag, fscale)
+
+
+def resize(image, opts, cb):
+    if not callable(cb):
+        raise PichaError("expected: resize(image, opts, cb)")
+    src, dst, ftag, fscale = _prepare_resize(image, opts, "expected: resize(image, opts, cb)")
+
+    def work():
+        try:
+            out = _run_resize(src, dst, ftag, fscale)
+        except Exception as e:  # device failure: not a class of error the reference has
+            cb(e, None)
+            return
+        cb(None, out)
+
+    return _executor().submit(work)
+
+
+def _color_settings(opts):
+    """getSettings (src/colorconvert.cc:6-22): NumberValue of each weight, NaN keeps the default."""
+    vals = []
+    for k in ("redWeight", "greenWeight", "blueWeight"):
+        v = _get(opts, k)
+        try:
+            vals.append(float(v) if v is not None else float("nan"))
+        except (TypeError, ValueError):
+            vals.append(float("nan"))
+    out = (ctypes.c_float * 3)()
+    N.lib().picha_color_settings(vals[0], vals[1], vals[2], out)
+    return out[0], out[1], out[2]
+
+
+def _prepare_convert(image, opts, expected):
+    if not _is_object(image) or not _is_object(opts):
+        raise PichaError(expected)
+    src = _native_image(image)
+    if src is None:
+        raise PichaError("invalid image")
+    to_pixel = _get(opts, "pixel")
+    if not isinstance(to_pixel, str) or N.pixel_index(to_pixel) < 0:
+        raise PichaError("expected pixel mode")
+    dst = _new_image(src[0].width, src[0].height, to_pixel)
+    return src, dst, _color_settings(opts)
+
+
+def _run_convert(src, dst, cs):
+    cdst = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index(dst.pixel))
+    N.check(N.lib().picha_hip_color_convert(ctypes.byref(src[0]), ctypes.byref(cdst), cs[0], cs[1], cs[2]))
+    return dst
+
+
+def colorConvertSync(image, opts):
+    src, dst, cs = _prepare_convert(image, opts, "expected: colorConvertSync(image, opts)")
+    return _run_convert(src, dst, cs)
+
+
+def colorConvert(image, opts, cb):
+    if not callable(cb):
+        raise PichaError("expected: colorConvert(image, opts, cb)")
+    src, dst, cs = _prepare_convert(image, opts, "expected: colorConvert(image, opts, cb)")
+
+    def work():
+        try:
+            out = _run_convert(src, dst, cs)
+        except Exception as e:
+            cb(e, None)
+            return
+        cb(None, out)
+
+    return _executor().submit(work)
+
+
+# ---- helpers exposed for tests / tools ----------------------------------------------------------
+def make_contribs(filter, filter_scale, src_size, dst_size):
+    """The product's host tap builder (picha_amd/csrc/taps.cpp) -> (left, right, weights[dst, T])."""
+    L = N.lib()
+    tag = N.FILTERS.index(filter) if isinstance(filter, str) else int(filter)
+    taps = ctypes.c_int(0)
+    cap = 8
+    while True:
+        left = np.zeros(dst_size, np.int32)
+        right = np.zeros(dst_size, np.int32)
+        w = np.zeros((dst_size, cap), np.float32)
+        rc = L.picha_hip_make_contribs(tag, filter_scale, src_size, dst_size, left.ctypes.data, right.ctypes.data,
+                                       w.ctypes.data, cap, ctypes.byref(taps))
+        if rc != 0 and taps.value > cap:
+            cap = taps.value
+            continue
+        N.check(rc)
+        return left, right, w[:, : taps.value].copy()
+
+
+def color_settings(red=None, green=None, blue=None):
+    return _color_settings({"redWeight": red, "greenWeight": green, "blueWeight": blue})

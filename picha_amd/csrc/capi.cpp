@@ -1,0 +1,763 @@
+// capi.cpp — the C ABI of libpicha_hip.so (include/picha_hip.h): validation, per-device tap-table
+// cache, launch planning, host staging.  Compiled by hipcc as host code.  No CPU compute path
+// lives here: every pixel is produced by the kernels in kernels.hip.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <tuple>
+#include <vector>
+
+#include "../../include/picha_hip.h"
+#include "kernels.h"
+#include "taps.h"
+
+using namespace picha_hip;
+
+namespace {
+
+// ---- error plumbing ----------------------------------------------------------------------------
+thread_local std::string g_last_error;
+thread_local const char *g_last_kernel = "";
+
+int fail(int status, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return status;
+}
+
+#define HIP_TRY(expr)                                                                           \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(PICHA_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));          \
+    } while (0)
+
+// ---- format tables (src/picha.h:118-200, src/picha.cc:36-39, src/resize.cc:162-164) -------------
+const int kBytes[8] = {3, 4, 1, 2, 2, 4, 6, 8};
+const int kChannels[8] = {3, 4, 1, 2, 1, 2, 3, 4};
+const char *const kPixelNames[8] = {"rgb", "rgba", "grey", "greya", "r16", "r16g16", "r16g16b16", "r16g16b16a16"};
+const char *const kFilterNames[6] = {"cubic", "lanczos", "catmulrom", "mitchel", "box", "triangle"};
+
+bool valid_pixel(int p) { return p >= 0 && p < PICHA_NUM_PIXELS; }
+
+// ---- options -----------------------------------------------------------------------------------
+std::mutex g_opt_mu;
+long g_opt_path = 0;        // 0 auto, 1 two-pass, 2 fused (error if unsupported)
+long g_opt_row_chunks = 0;  // 0 auto
+
+// ---- per-device state ---------------------------------------------------------------------------
+struct DeviceAxis {
+    AxisTaps host;
+    void *blob = nullptr;  // one allocation holding every table below
+    // generic (two-pass) tables
+    int32_t *left = nullptr, *count = nullptr, *eff = nullptr;
+    float *weight = nullptr;  // [dst][taps]
+    // fused, x role
+    int32_t *x_left = nullptr;  // shifted so x_left + taps <= src
+    float *x_weight = nullptr;  // [taps][dst]
+    // fused, y role
+    int4 *y_info = nullptr;
+    float *y_weight = nullptr;  // [dst][y_pad]
+    int32_t *y_slot = nullptr;  // [dst][y_pad]
+    int y_pad = 0;
+};
+
+using AxisKey = std::tuple<int, uint32_t, int, int>;
+
+// A reusable device (+ optional pinned host) buffer whose successive uses are ordered by an event:
+// the next user, on whatever stream, waits for the previous use to finish.  hipMallocAsync is
+// deliberately not used anywhere: on this stack (ROCm 7.2, gfx950) kernels that read or wrote
+// freshly pool-allocated memory intermittently saw stale data.
+struct TempBuf {
+    void *dev = nullptr;
+    size_t dev_cap = 0;
+    void *host = nullptr;  // pinned
+    size_t host_cap = 0;
+    hipEvent_t ev = nullptr;
+    bool pending = false;
+};
+
+struct DeviceCtx {
+    std::mutex mu;
+    std::map<AxisKey, std::unique_ptr<DeviceAxis>> axes;
+    std::mutex temp_mu;  // held from temp_acquire to temp_release
+    TempBuf scratch;     // two-pass float scratch
+    TempBuf tables;      // per-image pointer tables
+};
+
+std::mutex g_ctx_mu;
+std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
+
+int current_device(int *dev) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(PICHA_ERR_NO_DEVICE, "no HIP device available (%s)", hipGetErrorString(e));
+    HIP_TRY(hipGetDevice(dev));
+    return PICHA_OK;
+}
+
+DeviceCtx *ctx_for(int dev) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    auto &p = g_ctx[dev];
+    if (!p) p.reset(new DeviceCtx);
+    return p.get();
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// Caller holds ctx->temp_mu.  After this returns, work enqueued on `s` may use t.dev[0, dev_bytes)
+// and the host may write t.host[0, host_bytes).
+int temp_acquire(TempBuf &t, size_t dev_bytes, size_t host_bytes, hipStream_t s) {
+    if (!t.ev) HIP_TRY(hipEventCreateWithFlags(&t.ev, hipEventDisableTiming));
+    const bool grow = dev_bytes > t.dev_cap || host_bytes > t.host_cap;
+    if (t.pending) {
+        if (grow || host_bytes > 0) HIP_TRY(hipEventSynchronize(t.ev));  // host side is about to be reused
+        else HIP_TRY(hipStreamWaitEvent(s, t.ev, 0));
+        if (grow || host_bytes > 0) t.pending = false;
+    }
+    if (dev_bytes > t.dev_cap) {
+        if (t.dev) HIP_TRY(hipFree(t.dev));
+        t.dev = nullptr; t.dev_cap = 0;
+        const size_t cap = align_up(dev_bytes + dev_bytes / 4, 1 << 20);
+        HIP_TRY(hipMalloc(&t.dev, cap));
+        t.dev_cap = cap;
+    }
+    if (host_bytes > t.host_cap) {
+        if (t.host) HIP_TRY(hipHostFree(t.host));
+        t.host = nullptr; t.host_cap = 0;
+        const size_t cap = align_up(host_bytes * 2, 1 << 16);
+        HIP_TRY(hipHostMalloc(&t.host, cap, hipHostMallocDefault));
+        t.host_cap = cap;
+    }
+    return PICHA_OK;
+}
+int temp_release(TempBuf &t, hipStream_t s) {
+    HIP_TRY(hipEventRecord(t.ev, s));
+    t.pending = true;
+    return PICHA_OK;
+}
+
+// Builds (once) and uploads the tables for one axis.  Synchronous on first use of a geometry;
+// afterwards a pure lookup.
+int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, const DeviceAxis **out) {
+    uint32_t bits;
+    memcpy(&bits, &fscale, 4);
+    AxisKey key(filter, bits, src, dst);
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ctx->axes.find(key);
+    if (it != ctx->axes.end()) {
+        *out = it->second.get();
+        return PICHA_OK;
+    }
+    std::unique_ptr<DeviceAxis> ax(new DeviceAxis);
+    int rc = build_axis_taps(filter, fscale, src, dst, ax->host);
+    if (rc != PICHA_OK) return fail(rc, "%s", picha_hip_strerror(rc));
+    const AxisTaps &t = ax->host;
+    const int T = t.taps;
+    const int YP = fused_y_pad(T);
+    ax->y_pad = YP;
+
+    // host-side images of the device tables
+    std::vector<int32_t> x_left(dst);
+    std::vector<float> x_weight((size_t)T * dst, 0.0f);
+    for (int i = 0; i < dst; ++i) {
+        // keep every tap address in range with a fixed tap count: shift the window left and pad
+        // zeros in FRONT (0 * finite sample contributes +-0 and leaves the sum unchanged)
+        int l = t.left[i], shift = 0;
+        if (l + T > src) { shift = l + T - src; l = src - T; }
+        x_left[i] = l;
+        for (int j = 0; j < t.count[i]; ++j) x_weight[(size_t)(j + shift) * dst + i] = t.weight[(size_t)i * T + j];
+    }
+    std::vector<int4> y_info(dst);
+    std::vector<float> y_weight((size_t)dst * YP, 0.0f);
+    std::vector<int32_t> y_slot((size_t)dst * YP, 0);
+    const int ring = std::max(t.span, 1);
+    for (int i = 0; i < dst; ++i) {
+        y_info[i] = make_int4(t.left[i], t.need[i], t.count[i], 0);
+        for (int j = 0; j < YP; ++j) {
+            const int jj = j < T ? j : 0;
+            y_weight[(size_t)i * YP + j] = j < T ? t.weight[(size_t)i * T + j] : 0.0f;
+            y_slot[(size_t)i * YP + j] = t.eff[(size_t)i * T + jj] % ring;
+        }
+    }
+
+    struct Part { const void *src; size_t bytes; void **dst; };
+    Part parts[] = {
+        {t.left.data(), sizeof(int32_t) * dst, (void **)&ax->left},
+        {t.count.data(), sizeof(int32_t) * dst, (void **)&ax->count},
+        {t.eff.data(), sizeof(int32_t) * (size_t)dst * T, (void **)&ax->eff},
+        {t.weight.data(), sizeof(float) * (size_t)dst * T, (void **)&ax->weight},
+        {x_left.data(), sizeof(int32_t) * dst, (void **)&ax->x_left},
+        {x_weight.data(), sizeof(float) * (size_t)dst * T, (void **)&ax->x_weight},
+        {y_info.data(), sizeof(int4) * dst, (void **)&ax->y_info},
+        {y_weight.data(), sizeof(float) * (size_t)dst * YP, (void **)&ax->y_weight},
+        {y_slot.data(), sizeof(int32_t) * (size_t)dst * YP, (void **)&ax->y_slot},
+    };
+    size_t total = 0;
+    for (auto &p : parts) total += align_up(p.bytes, 256);
+    std::vector<uint8_t> image(total, 0);
+    HIP_TRY(hipMalloc(&ax->blob, total));
+    size_t off = 0;
+    for (auto &p : parts) {
+        memcpy(image.data() + off, p.src, p.bytes);
+        *p.dst = static_cast<uint8_t *>(ax->blob) + off;
+        off += align_up(p.bytes, 256);
+    }
+    HIP_TRY(hipMemcpy(ax->blob, image.data(), total, hipMemcpyHostToDevice));
+    *out = ax.get();
+    ctx->axes[key] = std::move(ax);
+    return PICHA_OK;
+}
+
+// ---- validation ----------------------------------------------------------------------------------
+int check_src(const picha_image *im) {
+    // jsImageToNativeImage (src/picha.cc:61-85): valid pixel, data present, height != 0
+    if (!im || !im->data || !valid_pixel(im->pixel) || im->height <= 0 || im->width <= 0 || im->stride < 0)
+        return fail(PICHA_ERR_INVALID_IMAGE, "invalid image");
+    return PICHA_OK;
+}
+int check_dst(const picha_image *im) {
+    if (!im || !im->data || !valid_pixel(im->pixel)) return fail(PICHA_ERR_INVALID_IMAGE, "invalid image");
+    if (im->width <= 0 || im->height <= 0) return fail(PICHA_ERR_INVALID_DIMENSIONS, "invalid dimensions");
+    if (im->stride < im->width * kBytes[im->pixel]) return fail(PICHA_ERR_INVALID_IMAGE, "invalid image");
+    return PICHA_OK;
+}
+size_t image_span(const picha_image &im) {  // bytes from data to the end of the last row's payload
+    return (size_t)(im.height - 1) * (size_t)im.stride + (size_t)im.width * kBytes[im.pixel];
+}
+
+bool same_geometry(const picha_image &a, const picha_image &b) {
+    return a.stride == b.stride && a.width == b.width && a.height == b.height && a.pixel == b.pixel;
+}
+
+// natural alignment the fused kernel's typed loads need
+int fused_align(int pixel) {
+    switch (pixel) {
+    case PICHA_RGB: case PICHA_GREY: return 1;
+    case PICHA_GREYA: case PICHA_R16: case PICHA_R16G16B16: return 2;
+    case PICHA_RGBA: case PICHA_R16G16: return 4;
+    default: return 8;
+    }
+}
+
+struct TablePair {  // device pointer tables for a group with non-uniform pitch
+    const void *const *src = nullptr;
+    void *const *dst = nullptr;
+    bool used = false;
+};
+
+// Uniform pitch?  (data[i] = data[0] + i * pitch)
+bool uniform_pitch(const picha_image *im, int n, long long *pitch) {
+    *pitch = 0;
+    if (n <= 1) return true;
+    const long long p = (const char *)im[1].data - (const char *)im[0].data;
+    for (int i = 2; i < n; ++i)
+        if ((const char *)im[i].data - (const char *)im[i - 1].data != p) return false;
+    *pitch = p;
+    return true;
+}
+
+// Caller holds ctx->temp_mu and calls temp_release(ctx->tables, s) after the launches.
+int make_tables(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, hipStream_t s, TablePair *t) {
+    const size_t bytes = sizeof(void *) * 2 * (size_t)n;
+    int rc = temp_acquire(ctx->tables, bytes, bytes, s);
+    if (rc) return rc;
+    const void **h = static_cast<const void **>(ctx->tables.host);
+    for (int i = 0; i < n; ++i) { h[i] = src[i].data; h[n + i] = dst[i].data; }
+    HIP_TRY(hipMemcpyAsync(ctx->tables.dev, h, bytes, hipMemcpyHostToDevice, s));
+    t->src = static_cast<const void *const *>(ctx->tables.dev);
+    t->dst = reinterpret_cast<void *const *>(static_cast<void **>(ctx->tables.dev) + n);
+    t->used = true;
+    return PICHA_OK;
+}
+
+// ---- resize of one equal-geometry group on device ------------------------------------------------
+int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, int filter,
+                 float fscale, hipStream_t s) {
+    const picha_image &s0 = src[0], &d0 = dst[0];
+    const int pixel = s0.pixel;
+    const DeviceAxis *ax = nullptr, *ay = nullptr;
+    int rc = get_axis(ctx, filter, fscale, s0.width, d0.width, &ax);
+    if (rc) return rc;
+    rc = get_axis(ctx, filter, fscale, s0.height, d0.height, &ay);
+    if (rc) return rc;
+
+    long opt_path, opt_chunks;
+    { std::lock_guard<std::mutex> lk(g_opt_mu); opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; }
+
+    const int ring = std::max(ay->host.span, 1);
+    bool fused_ok = fused_supported(pixel, ax->host.taps, ay->host.taps, ring);
+    const int al = fused_align(pixel);
+    for (int i = 0; i < n && fused_ok; ++i) {
+        if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) fused_ok = false;
+        if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % al) fused_ok = false;
+    }
+    if (opt_path == 2 && !fused_ok) return fail(PICHA_ERR_ARGUMENT, "fused kernel forced but unsupported for this geometry");
+    const bool use_fused = fused_ok && opt_path != 1;
+
+    if (use_fused) {
+        FusedParams p{};
+        long long sp = 0, dp = 0;
+        TablePair tab;
+        std::unique_lock<std::mutex> temp_lock(ctx->temp_mu, std::defer_lock);
+        if (uniform_pitch(src, n, &sp) && uniform_pitch(dst, n, &dp)) {
+            p.src = static_cast<const uint8_t *>(s0.data);
+            p.dst = static_cast<uint8_t *>(d0.data);
+            p.src_pitch = sp;
+            p.dst_pitch = dp;
+        } else {
+            temp_lock.lock();
+            rc = make_tables(ctx, src, dst, n, s, &tab);
+            if (rc) return rc;
+            p.src_tab = tab.src;
+            p.dst_tab = tab.dst;
+        }
+        p.src_stride = s0.stride; p.dst_stride = d0.stride;
+        p.src_w = s0.width; p.src_h = s0.height; p.dst_w = d0.width; p.dst_h = d0.height;
+        p.n_images = n;
+        p.x_left = ax->x_left; p.x_weight = ax->x_weight; p.x_taps = ax->host.taps;
+        p.y_info = ay->y_info; p.y_weight = ay->y_weight; p.y_slot = ay->y_slot;
+        p.y_taps = ay->host.taps; p.y_pad = ay->y_pad;
+        p.ring_slots = ring;
+        // row chunks: enough waves to fill 256 CUs several times over, chunks not too short
+        const long long col_waves = (d0.width + 63) / 64;
+        long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
+        chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
+        p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
+        p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
+        // grid.z limit
+        int done = 0;
+        while (done < n) {
+            const int m = std::min(n - done, 65535);
+            FusedParams q = p;
+            q.n_images = m;
+            if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
+            else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
+            HIP_TRY(launch_resize_fused(pixel, q, s, &g_last_kernel));
+            done += m;
+        }
+        if (tab.used) return temp_release(ctx->tables, s);
+        return PICHA_OK;
+    }
+
+    // two-pass through a stream-ordered scratch, one image at a time
+    const AxisTaps &ty = ay->host;
+    const int row0 = ty.first_row;
+    const int nrows = ty.need[d0.height - 1] - row0 + 1;
+    const size_t scratch_bytes = sizeof(float) * (size_t)nrows * d0.width * kChannels[pixel];
+    std::lock_guard<std::mutex> temp_lock(ctx->temp_mu);
+    rc = temp_acquire(ctx->scratch, scratch_bytes, 0, s);
+    if (rc) return rc;
+    float *scratch = static_cast<float *>(ctx->scratch.dev);
+    for (int i = 0; i < n; ++i) {
+        TwoPassParams p{};
+        p.src = static_cast<const uint8_t *>(src[i].data);
+        p.dst = static_cast<uint8_t *>(dst[i].data);
+        p.src_stride = src[i].stride; p.dst_stride = dst[i].stride;
+        p.src_w = s0.width; p.src_h = s0.height; p.dst_w = d0.width; p.dst_h = d0.height;
+        p.x_left = ax->left; p.x_count = ax->count; p.x_weight = ax->weight; p.x_taps = ax->host.taps;
+        p.y_count = ay->count; p.y_eff = ay->eff; p.y_weight = ay->weight; p.y_taps = ay->host.taps;
+        p.row0 = row0; p.nrows = nrows; p.scratch = scratch;
+        HIP_TRY(launch_resize_twopass(pixel, p, s));
+    }
+    g_last_kernel = "twopass";
+    return temp_release(ctx->scratch, s);
+}
+
+int convert_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, float r, float g, float b, hipStream_t s) {
+    const picha_image &s0 = src[0], &d0 = dst[0];
+    if (s0.pixel == d0.pixel) {
+        // doColorConvert same-format branch: NativeImage::copy, payload bytes only (src/picha.cc:27-34)
+        const size_t rw = (size_t)s0.width * kBytes[s0.pixel];
+        for (int i = 0; i < n; ++i)
+            HIP_TRY(hipMemcpy2DAsync(dst[i].data, dst[i].stride, src[i].data, src[i].stride, rw, s0.height,
+                                      hipMemcpyDeviceToDevice, s));
+        return PICHA_OK;
+    }
+    ConvertParams p{};
+    long long sp = 0, dp = 0;
+    TablePair tab;
+    std::unique_lock<std::mutex> temp_lock(ctx->temp_mu, std::defer_lock);
+    if (uniform_pitch(src, n, &sp) && uniform_pitch(dst, n, &dp)) {
+        p.src = static_cast<const uint8_t *>(s0.data);
+        p.dst = static_cast<uint8_t *>(d0.data);
+        p.src_pitch = sp; p.dst_pitch = dp;
+    } else {
+        temp_lock.lock();
+        int rc = make_tables(ctx, src, dst, n, s, &tab);
+        if (rc) return rc;
+        p.src_tab = tab.src; p.dst_tab = tab.dst;
+    }
+    p.src_stride = s0.stride; p.dst_stride = d0.stride;
+    p.width = s0.width; p.height = s0.height;
+    p.r = r; p.g = g; p.b = b;
+    int done = 0;
+    while (done < n) {
+        const int m = std::min(n - done, 65535);
+        ConvertParams q = p;
+        q.n_images = m;
+        if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
+        else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
+        HIP_TRY(launch_color_convert(s0.pixel, d0.pixel, q, s));
+        done += m;
+    }
+    if (tab.used) return temp_release(ctx->tables, s);
+    return PICHA_OK;
+}
+
+// per-thread, per-device stream for the host-pointer entry points
+int host_stream(int dev, hipStream_t *out) {
+    thread_local std::map<int, hipStream_t> streams;
+    auto it = streams.find(dev);
+    if (it == streams.end()) {
+        hipStream_t s;
+        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        it = streams.emplace(dev, s).first;
+    }
+    *out = it->second;
+    return PICHA_OK;
+}
+
+// per-thread pinned host staging buffer (grow-only)
+int pinned_staging(size_t bytes, uint8_t **out) {
+    struct Buf { uint8_t *p = nullptr; size_t cap = 0; };
+    thread_local Buf b;
+    if (b.cap < bytes) {
+        if (b.p) (void)hipHostFree(b.p);
+        b.p = nullptr; b.cap = 0;
+        size_t cap = align_up(bytes + bytes / 4, 1 << 20);
+        HIP_TRY(hipHostMalloc((void **)&b.p, cap, hipHostMallocDefault));
+        b.cap = cap;
+    }
+    *out = b.p;
+    return PICHA_OK;
+}
+
+// per-thread, per-device arena for the host-pointer entry points (grow-only; only ever used on
+// this thread's own stream, and every call ends with a stream synchronise)
+int device_arena(int dev, size_t bytes, uint8_t **out) {
+    struct Buf { uint8_t *p = nullptr; size_t cap = 0; };
+    thread_local std::map<int, Buf> arenas;
+    Buf &b = arenas[dev];
+    if (b.cap < bytes) {
+        if (b.p) HIP_TRY(hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+        const size_t cap = align_up(bytes + bytes / 4, 1 << 20);
+        HIP_TRY(hipMalloc((void **)&b.p, cap));
+        b.cap = cap;
+    }
+    *out = b.p;
+    return PICHA_OK;
+}
+
+enum class Op { Resize, Convert };
+
+// Shared host-pointer driver: stage in, run the device entry point, stage out payload rows.
+int run_host(Op op, int n, const picha_image *src, const picha_image *dst, int filter, float fscale,
+             float r, float g, float b) {
+    if (n < 0 || (n > 0 && (!src || !dst))) return fail(PICHA_ERR_ARGUMENT, "bad batch arguments");
+    if (n == 0) return PICHA_OK;
+    for (int i = 0; i < n; ++i) {
+        int rc = check_src(&src[i]);
+        if (rc) return rc;
+        rc = check_dst(&dst[i]);
+        if (rc) return rc;
+    }
+    int dev;
+    int rc = current_device(&dev);
+    if (rc) return rc;
+    hipStream_t s;
+    rc = host_stream(dev, &s);
+    if (rc) return rc;
+
+    // one device arena and one pinned host mirror of it: [src images | dst images], 256-byte aligned.
+    // Transfers go through the pinned mirror as two 1-D copies (pageable / 2-D async copies are
+    // staged by the runtime anyway, and were observed to complete after hipStreamSynchronize).
+    std::vector<size_t> soff(n), doff(n);
+    size_t total = 0;
+    for (int i = 0; i < n; ++i) { soff[i] = total; total += align_up(image_span(src[i]), 256); }
+    const size_t dst_begin = total;
+    for (int i = 0; i < n; ++i) { doff[i] = total; total += align_up(image_span(dst[i]), 256); }
+    uint8_t *pinned = nullptr;
+    rc = pinned_staging(total + 256, &pinned);
+    if (rc) return rc;
+    uint8_t *arena = nullptr;
+    rc = device_arena(dev, total + 256, &arena);
+    if (rc) return rc;
+    std::vector<picha_image> dsrc(src, src + n), ddst(dst, dst + n);
+    for (int i = 0; i < n; ++i) {
+        dsrc[i].data = arena + soff[i];
+        ddst[i].data = arena + doff[i];
+        memcpy(pinned + soff[i], src[i].data, image_span(src[i]));
+    }
+    hipError_t e0 = hipMemcpyAsync(arena, pinned, dst_begin, hipMemcpyHostToDevice, s);
+    if (e0 != hipSuccess) rc = fail(PICHA_ERR_HIP, "H2D failed: %s", hipGetErrorString(e0));
+    if (rc == PICHA_OK)
+        rc = (op == Op::Resize) ? picha_hip_resize_device(n, dsrc.data(), ddst.data(), filter, fscale, s)
+                                : picha_hip_color_convert_device(n, dsrc.data(), ddst.data(), r, g, b, s);
+    if (rc == PICHA_OK) {
+        hipError_t e = hipMemcpyAsync(pinned + dst_begin, arena + dst_begin, total - dst_begin, hipMemcpyDeviceToHost, s);
+        if (e != hipSuccess) rc = fail(PICHA_ERR_HIP, "D2H failed: %s", hipGetErrorString(e));
+    }
+    hipError_t e2 = hipStreamSynchronize(s);
+    if (rc == PICHA_OK && e2 != hipSuccess)
+        rc = fail(PICHA_ERR_HIP, "stream completion failed: %s", hipGetErrorString(e2));
+    if (rc == PICHA_OK) {
+        for (int i = 0; i < n; ++i) {
+            // payload bytes only: dst row padding is never written (src/resize.cc:122-132, src/picha.cc:27-34)
+            const size_t rw = (size_t)dst[i].width * kBytes[dst[i].pixel];
+            const uint8_t *from = pinned + doff[i];
+            uint8_t *to = static_cast<uint8_t *>(dst[i].data);
+            if ((size_t)dst[i].stride == rw) memcpy(to, from, rw * dst[i].height);
+            else for (int y = 0; y < dst[i].height; ++y) memcpy(to + (size_t)y * dst[i].stride, from + (size_t)y * dst[i].stride, rw);
+        }
+    }
+    return rc;
+}
+
+}  // namespace
+
+// ================================================================================================
+// C ABI
+// ================================================================================================
+extern "C" {
+
+int picha_pixel_bytes(int pixel) { return valid_pixel(pixel) ? kBytes[pixel] : 0; }
+int picha_pixel_channels(int pixel) { return valid_pixel(pixel) ? kChannels[pixel] : 0; }
+int picha_row_stride(int width, int pixel) { return (picha_pixel_bytes(pixel) * width + 3) & ~3; }
+
+int picha_pixel_from_name(const char *name) {
+    if (!name) return PICHA_INVALID_PIXEL;
+    for (int i = 0; i < 8; ++i)
+        if (strcmp(name, kPixelNames[i]) == 0) return i;
+    return PICHA_INVALID_PIXEL;
+}
+const char *picha_pixel_name(int pixel) { return valid_pixel(pixel) ? kPixelNames[pixel] : nullptr; }
+int picha_filter_from_name(const char *name) {
+    if (!name) return -1;
+    for (int i = 0; i < 6; ++i)
+        if (strcmp(name, kFilterNames[i]) == 0) return i;
+    return -1;
+}
+const char *picha_filter_name(int f) { return (f >= 0 && f < 6) ? kFilterNames[f] : nullptr; }
+
+int picha_resize_options(int has_filter, int filter, int has_filter_scale, double filter_scale,
+                         int *out_filter, float *out_scale) {
+    // ResizeOptions() : filter(CubicFilterTag), width(0.70f)   src/resize.cc:173-177
+    int f = PICHA_FILTER_CUBIC;
+    float w = 0.70f;
+    if (has_filter) {  // src/resize.cc:181-188
+        w = 1.0f;
+        f = filter;
+        if (f < 0 || f >= PICHA_NUM_FILTERS) return fail(PICHA_ERR_INVALID_FILTER, "invalid filter mode");
+    }
+    if (has_filter_scale) {  // src/resize.cc:190-196
+        w = (float)filter_scale;
+        if (w != w || w <= 0) return fail(PICHA_ERR_INVALID_FILTER_WIDTH, "invalid filter width");
+    }
+    if (out_filter) *out_filter = f;
+    if (out_scale) *out_scale = w;
+    return PICHA_OK;
+}
+
+void picha_color_settings(double red, double green, double blue, float out[3]) {
+    // ColorSettings() src/colorconvert.h:11-14 ; getSettings src/colorconvert.cc:6-22
+    float rf = 0.299f, gf = 0.587f, bf = float(0.114);
+    if (red == red) rf = (float)red;
+    if (green == green) gf = (float)green;
+    if (blue == blue) bf = (float)blue;
+    const float n = 1.0f / (rf + gf + bf);
+    out[0] = rf * n;
+    out[1] = gf * n;
+    out[2] = bf * n;
+}
+
+int picha_hip_make_contribs(int filter, float filter_scale, int src_size, int dst_size, int32_t *left,
+                            int32_t *right, float *weights, int max_taps, int *taps_out) {
+    if (!left || !right || !weights) return fail(PICHA_ERR_ARGUMENT, "null output");
+    AxisTaps t;
+    int rc = build_axis_taps(filter, filter_scale, src_size, dst_size, t);
+    if (rc) return fail(rc, "%s", picha_hip_strerror(rc));
+    if (taps_out) *taps_out = t.taps;
+    if (t.taps > max_taps) return fail(PICHA_ERR_ARGUMENT, "max_taps too small: need %d", t.taps);
+    for (int i = 0; i < dst_size; ++i) {
+        left[i] = t.left[i];
+        right[i] = t.left[i] + t.count[i] - 1;
+        for (int j = 0; j < max_taps; ++j) weights[(size_t)i * max_taps + j] = j < t.taps ? t.weight[(size_t)i * t.taps + j] : 0.0f;
+    }
+    return PICHA_OK;
+}
+
+const char *picha_hip_last_error(void) { return g_last_error.c_str(); }
+const char *picha_hip_last_kernel(void) { return g_last_kernel; }
+
+const char *picha_hip_strerror(int status) {
+    switch (status) {
+    case PICHA_OK: return "ok";
+    case PICHA_ERR_INVALID_IMAGE: return "invalid image";
+    case PICHA_ERR_INVALID_DIMENSIONS: return "invalid dimensions";
+    case PICHA_ERR_INVALID_FILTER: return "invalid filter mode";
+    case PICHA_ERR_INVALID_FILTER_WIDTH: return "invalid filter width";
+    case PICHA_ERR_PIXEL_MISMATCH: return "pixel format or size mismatch between source and destination";
+    case PICHA_ERR_EXPECTED_PIXEL: return "expected pixel mode";
+    case PICHA_ERR_DEGENERATE_TAPS: return "filter taps sum to a non-positive weight";
+    case PICHA_ERR_NO_DEVICE: return "no HIP device available";
+    case PICHA_ERR_HIP: return "HIP runtime failure";
+    case PICHA_ERR_ARGUMENT: return "invalid argument";
+    }
+    return "unknown status";
+}
+
+int picha_hip_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int picha_hip_device_arch(char *buf, size_t len) {
+    int dev;
+    int rc = current_device(&dev);
+    if (rc) return rc;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, len, "%s", prop.gcnArchName);
+    return PICHA_OK;
+}
+
+int picha_hip_set_option(const char *key, long value) {
+    if (!key) return fail(PICHA_ERR_ARGUMENT, "null key");
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (strcmp(key, "path") == 0) { g_opt_path = value; return PICHA_OK; }
+    if (strcmp(key, "row_chunks") == 0) { g_opt_row_chunks = value; return PICHA_OK; }
+    return fail(PICHA_ERR_ARGUMENT, "unknown option %s", key);
+}
+long picha_hip_get_option(const char *key) {
+    if (!key) return -1;
+    std::lock_guard<std::mutex> lk(g_opt_mu);
+    if (strcmp(key, "path") == 0) return g_opt_path;
+    if (strcmp(key, "row_chunks") == 0) return g_opt_row_chunks;
+    return -1;
+}
+
+// ---- device-resident entry points ---------------------------------------------------------------
+int picha_hip_resize_device(int n, const picha_image *src, const picha_image *dst, int filter,
+                            float filter_scale, void *stream) {
+    if (n < 0 || (n > 0 && (!src || !dst))) return fail(PICHA_ERR_ARGUMENT, "bad batch arguments");
+    if (filter < 0 || filter >= PICHA_NUM_FILTERS) return fail(PICHA_ERR_INVALID_FILTER, "invalid filter mode");
+    if (!(filter_scale > 0)) return fail(PICHA_ERR_INVALID_FILTER_WIDTH, "invalid filter width");
+    for (int i = 0; i < n; ++i) {
+        int rc = check_src(&src[i]);
+        if (rc) return rc;
+        rc = check_dst(&dst[i]);
+        if (rc) return rc;
+        if (src[i].pixel != dst[i].pixel)  // assert(src.pixel == dst.pixel) src/resize.cc:137
+            return fail(PICHA_ERR_PIXEL_MISMATCH, "resize: source and destination pixel formats differ");
+    }
+    if (n == 0) return PICHA_OK;
+    int dev;
+    int rc = current_device(&dev);
+    if (rc) return rc;
+    DeviceCtx *ctx = ctx_for(dev);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int i = 0;
+    while (i < n) {  // runs of equal geometry -> one launch each
+        int j = i + 1;
+        while (j < n && same_geometry(src[j], src[i]) && same_geometry(dst[j], dst[i])) ++j;
+        rc = resize_group(ctx, src + i, dst + i, j - i, filter, filter_scale, s);
+        if (rc) return rc;
+        i = j;
+    }
+    return PICHA_OK;
+}
+
+int picha_hip_color_convert_device(int n, const picha_image *src, const picha_image *dst, float r,
+                                   float g, float b, void *stream) {
+    if (n < 0 || (n > 0 && (!src || !dst))) return fail(PICHA_ERR_ARGUMENT, "bad batch arguments");
+    for (int i = 0; i < n; ++i) {
+        int rc = check_src(&src[i]);
+        if (rc) return rc;
+        rc = check_dst(&dst[i]);
+        if (rc) return rc;
+        if (src[i].width != dst[i].width || src[i].height != dst[i].height)  // asserts src/colorconvert.cc:138-139
+            return fail(PICHA_ERR_PIXEL_MISMATCH, "colorConvert: source and destination sizes differ");
+    }
+    if (n == 0) return PICHA_OK;
+    int dev;
+    int rc = current_device(&dev);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int i = 0;
+    while (i < n) {
+        int j = i + 1;
+        while (j < n && same_geometry(src[j], src[i]) && same_geometry(dst[j], dst[i])) ++j;
+        rc = convert_group(ctx_for(dev), src + i, dst + i, j - i, r, g, b, s);
+        if (rc) return rc;
+        i = j;
+    }
+    return PICHA_OK;
+}
+
+// ---- host-pointer entry points --------------------------------------------------------------------
+int picha_hip_resize(const picha_image *src, const picha_image *dst, int filter, float filter_scale) {
+    return run_host(Op::Resize, 1, src, dst, filter, filter_scale, 0, 0, 0);
+}
+int picha_hip_color_convert(const picha_image *src, const picha_image *dst, float r, float g, float b) {
+    return run_host(Op::Convert, 1, src, dst, 0, 0, r, g, b);
+}
+int picha_hip_resize_batch(int n, const picha_image *src, const picha_image *dst, int filter, float filter_scale) {
+    return run_host(Op::Resize, n, src, dst, filter, filter_scale, 0, 0, 0);
+}
+int picha_hip_color_convert_batch(int n, const picha_image *src, const picha_image *dst, float r, float g, float b) {
+    return run_host(Op::Convert, n, src, dst, 0, 0, r, g, b);
+}
+
+// ---- device memory helpers --------------------------------------------------------------------------
+int picha_hip_malloc(void **dev_ptr, size_t bytes) {
+    if (!dev_ptr) return fail(PICHA_ERR_ARGUMENT, "null out pointer");
+    int dev;
+    int rc = current_device(&dev);
+    if (rc) return rc;
+    HIP_TRY(hipMalloc(dev_ptr, bytes));
+    return PICHA_OK;
+}
+int picha_hip_free(void *dev_ptr) {
+    HIP_TRY(hipFree(dev_ptr));
+    return PICHA_OK;
+}
+int picha_hip_memcpy_h2d(void *d, const void *h, size_t bytes, void *stream) {
+    HIP_TRY(hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    return PICHA_OK;
+}
+int picha_hip_memcpy_d2h(void *h, const void *d, size_t bytes, void *stream) {
+    HIP_TRY(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, static_cast<hipStream_t>(stream)));
+    return PICHA_OK;
+}
+int picha_hip_stream_synchronize(void *stream) {
+    HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return PICHA_OK;
+}
+int picha_hip_fill_random(void *dev_ptr, size_t bytes, uint64_t seed, int sample_bytes, void *stream) {
+    if (sample_bytes != 1 && sample_bytes != 2) return fail(PICHA_ERR_ARGUMENT, "sample_bytes must be 1 or 2");
+    int dev;
+    int rc = current_device(&dev);
+    if (rc) return rc;
+    HIP_TRY(launch_fill_random(dev_ptr, bytes, seed, sample_bytes, static_cast<hipStream_t>(stream)));
+    return PICHA_OK;
+}
+void picha_fill_random_host(void *host_ptr, size_t bytes, uint64_t seed, int sample_bytes) {
+    fill_random_host(host_ptr, bytes, seed, sample_bytes);
+}
+
+}  // extern "C"

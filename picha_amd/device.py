@@ -1,0 +1,129 @@
+"""Device-resident batches: images that already live in one GPU's HBM.
+
+torch is used here only as plumbing — it owns the device memory (uint8 tensors) and the HIP
+stream; every pixel is produced by libpicha_hip.so through the *_device entry points of the C
+ABI (include/picha_hip.h).  This is the path bench.py times and the path a service would use
+when decode and encode also run on the GPU.
+"""
+import ctypes
+
+import torch
+
+from . import _native as N
+
+
+def row_stride(width, pixel):
+    return (N.PIXEL_BYTES[pixel] * width + 3) & ~3
+
+
+class DeviceBatch:
+    """n equal-geometry images in one uint8 tensor [n, pitch] on a GPU (pitch >= height*stride)."""
+
+    def __init__(self, n, width, height, pixel, device="cuda", stride=None, tensor=None):
+        if N.pixel_index(pixel) < 0:
+            raise N.PichaError("invalid image")
+        self.n, self.width, self.height, self.pixel = int(n), int(width), int(height), pixel
+        self.stride = int(stride) if stride else row_stride(width, pixel)
+        # image pitch padded to 256 B so every image starts aligned for the widest loads
+        self.pitch = (self.height * self.stride + 255) // 256 * 256
+        if tensor is None:
+            tensor = torch.empty((self.n, self.pitch), dtype=torch.uint8, device=device)
+        assert tensor.dtype == torch.uint8 and tensor.is_contiguous() and tuple(tensor.shape) == (self.n, self.pitch)
+        self.tensor = tensor
+        self._desc = None
+
+    @property
+    def payload_bytes(self):
+        return self.n * self.height * self.width * N.PIXEL_BYTES[self.pixel]
+
+    def descriptors(self):
+        """ctypes array of picha_image with DEVICE pointers (cached; tensor storage must not move)."""
+        if self._desc is None or self._desc[1] != self.tensor.data_ptr():
+            base = self.tensor.data_ptr()
+            arr = (N.CImage * self.n)()
+            p = N.pixel_index(self.pixel)
+            for i in range(self.n):
+                arr[i] = N.CImage(base + i * self.pitch, self.stride, self.width, self.height, p)
+            self._desc = (arr, base)
+        return self._desc[0]
+
+    def fill_random(self, seed):
+        """Synthetic pixels (SURVEY.md 8d generator), generated on the device."""
+        sample = 2 if self.pixel.startswith("r16") else 1
+        stream = torch.cuda.current_stream(self.tensor.device).cuda_stream
+        with torch.cuda.device(self.tensor.device):
+            N.check(N.lib().picha_hip_fill_random(self.tensor.data_ptr(), self.tensor.numel(), seed, sample, stream))
+        return self
+
+    def image_host(self, i):
+        """Download image i as a host `Image`."""
+        from .image import Image
+        data = self.tensor[i, : self.height * self.stride].cpu().numpy().copy()
+        return Image(width=self.width, height=self.height, pixel=self.pixel, stride=self.stride, data=data)
+
+    def upload(self, i, image):
+        assert (image.width, image.height, image.pixel, image.stride) == (self.width, self.height, self.pixel, self.stride)
+        n = (self.height - 1) * self.stride + self.width * N.PIXEL_BYTES[self.pixel]
+        self.tensor[i, :n].copy_(torch.from_numpy(image.data[:n]))
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def resize_batch(src, dst_width=None, dst_height=None, filter=None, filter_scale=None, out=None, opts=None):
+    """picha.resize over a device-resident batch; same option semantics as resizeSync.
+
+    Asynchronous on torch's current stream.  Returns the destination DeviceBatch.
+    """
+    from .api import _resize_options
+    o = dict(opts or {})
+    if filter is not None:
+        o["filter"] = filter
+    if filter_scale is not None:
+        o["filterScale"] = filter_scale
+    ftag, fscale = _resize_options(o)
+    if out is None:
+        w = dst_width if dst_width is not None else o.get("width")
+        h = dst_height if dst_height is not None else o.get("height")
+        if not w or not h or w <= 0 or h <= 0:
+            raise N.PichaError("invalid dimensions")
+        out = DeviceBatch(src.n, w, h, src.pixel, device=src.tensor.device)
+    with torch.cuda.device(src.tensor.device):
+        N.check(N.lib().picha_hip_resize_device(src.n, src.descriptors(), out.descriptors(), ftag, fscale, _stream(src.tensor)))
+    return out
+
+
+def color_convert_batch(src, pixel, weights=None, out=None):
+    """picha.colorConvert over a device-resident batch (weights = normalised (r, g, b) or None)."""
+    from .api import color_settings
+    if N.pixel_index(pixel) < 0:
+        raise N.PichaError("expected pixel mode")
+    r, g, b = weights if weights is not None else color_settings()
+    if out is None:
+        out = DeviceBatch(src.n, src.width, src.height, pixel, device=src.tensor.device)
+    with torch.cuda.device(src.tensor.device):
+        N.check(N.lib().picha_hip_color_convert_device(src.n, src.descriptors(), out.descriptors(), r, g, b, _stream(src.tensor)))
+    return out
+
+
+class ResizePlan:
+    """Pre-marshalled resize of one batch into another: run() is a single C call (bench hot loop)."""
+
+    def __init__(self, src, dst, filter=None, filter_scale=None):
+        from .api import _resize_options
+        o = {}
+        if filter is not None:
+            o["filter"] = filter
+        if filter_scale is not None:
+            o["filterScale"] = filter_scale
+        self.ftag, self.fscale = _resize_options(o)
+        self.src, self.dst = src, dst
+        self._s, self._d = src.descriptors(), dst.descriptors()
+        self._fn = N.lib().picha_hip_resize_device
+
+    def run(self, stream=None):
+        st = stream if stream is not None else _stream(self.src.tensor)
+        rc = self._fn(self.src.n, self._s, self._d, self.ftag, self.fscale, st)
+        if rc:
+            N.check(rc)
