@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""bench.py — throughput of picha's pixel hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one device-resident batch of synthetic images
+(BASELINE.json configs[1]: 256 x 3840x2160 rgba -> 1920x1080, cubic).  One process per GPU; the
+batch is sharded by image (every rank owns its own 256 images — weak scaling, no data-path
+collective; RCCL is used only for the barrier and the max-over-ranks of the elapsed time).
+Inputs are resident in HBM before the timed region starts; the metric is whole-job source Mpix/s.
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     dominant kernel vs the HBM roof: algorithmic bytes per launch / measured launch time
+  cpu_baseline the CPU oracle (a port of the reference algorithm) timed on this box's host cores
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n_images, src_w, src_h, pixel, dst_w, dst_h, opts)
+    # picha.resize(img, {width, height}) — the library's default filter is cubic at filterScale 0.70
+    "cfg2_4k_rgba_to_1080p_cubic": (256, 3840, 2160, "rgba", 1920, 1080, {}),
+    "cfg2_4k_rgba_to_1080p_cubic_scale1": (256, 3840, 2160, "rgba", 1920, 1080, {"filter": "cubic"}),
+    "cfg1_640x480_rgba_to_320x240": (256, 640, 480, "rgba", 320, 240, {}),
+    "cfg3b_4k_grey_to_512_lanczos": (256, 3840, 2160, "grey", 512, 512, {"filter": "lanczos"}),
+    "cfg5_8k_rgba16_to_1080p_mitchel": (32, 7680, 4320, "r16g16b16a16", 1920, 1080, {"filter": "mitchel"}),
+}
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable copy)
+
+
+def cpu_baseline(name, budget_images=96):
+    """The oracle (CPU port of reference src/resize.cc:66-134) on a bounded sample of the workload."""
+    import numpy as np
+
+    import oracle
+    n, sw, sh, pixel, dw, dh, opts = WORKLOADS[name]
+    filt = opts.get("filter", "cubic")
+    fscale = opts.get("filterScale", 1.0 if "filter" in opts else 0.70)
+    threads = min(os.cpu_count() or 1, 32)
+    try:
+        threads = min(threads, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    bpp = {"rgba": 4, "grey": 1, "r16g16b16a16": 8, "rgb": 3}[pixel]
+    n_img = max(threads, min(budget_images, threads * 4))
+    if sw * sh * bpp > 100e6:
+        n_img = threads
+    distinct = min(n_img, 16)
+    rng = np.random.default_rng(20250226)
+    pool = [rng.integers(0, 256, size=sh * ((sw * bpp + 3) & ~3), dtype=np.uint8) for _ in range(distinct)]
+    srcs = [pool[i % distinct] for i in range(n_img)]
+    oracle.resize_batch_mt(srcs[:threads], sw, sh, pixel, dw, dh, filt, fscale, threads)  # warm
+    t0 = time.perf_counter()
+    oracle.resize_batch_mt(srcs, sw, sh, pixel, dw, dh, filt, fscale, threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": round(n_img * sw * sh / dt / 1e6, 2),
+        "unit": "Mpix/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": "%d images of the same workload (%d distinct), one image per thread on %d threads, %.2f s wall"
+                  % (n_img, distinct, threads, dt),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg2_4k_rgba_to_1080p_cubic", choices=sorted(WORKLOADS))
+    ap.add_argument("--images", type=int, default=0, help="override images per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--option", action="append", default=[], help="library knob key=value (e.g. row_chunks=4)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d"
+                  % (args.gpus, world, args.gpus), file=sys.stderr)
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    import picha_amd
+    from picha_amd import _native as N
+    from picha_amd.device import DeviceBatch, ResizePlan
+
+    for kv in args.option:
+        k, v = kv.split("=")
+        N.check(N.lib().picha_hip_set_option(k.encode(), int(v)))
+
+    n, sw, sh, pixel, dw, dh, opts = WORKLOADS[args.workload]
+    if args.images:
+        n = args.images
+    src = DeviceBatch(n, sw, sh, pixel, device=dev).fill_random(20250226 + 7919 * rank)
+    dst = DeviceBatch(n, dw, dh, pixel, device=dev)
+    plan = ResizePlan(src, dst, filter=opts.get("filter"), filter_scale=opts.get("filterScale"))
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        plan.run()
+    torch.cuda.synchronize()
+    kernel = N.lib().picha_hip_last_kernel().decode()
+
+    # per-launch durations from events on the launch stream (torch's current stream)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    evs[0].record()
+    for i in range(args.steps):
+        plan.run()
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
+    avg_launch_ms = sum(launch_ms) / len(launch_ms)
+
+    # parity sample: first image of this rank's batch against the oracle (the checker, not the product)
+    parity = None
+    if rank == 0 and not args.no_cpu_baseline:
+        import numpy as np
+
+        import oracle
+        img = src.image_host(0)
+        got = dst.image_host(0)
+        filt = opts.get("filter", "cubic")
+        fscale = opts.get("filterScale", 1.0 if "filter" in opts else 0.70)
+        exp, _ = oracle.resize(img.data, sw, sh, pixel, dw, dh, filt, fscale)
+        a = got.pixels().astype(np.int64)
+        b = picha_amd.Image(width=dw, height=dh, pixel=pixel, data=exp).pixels().astype(np.int64)
+        parity = int(np.abs(a - b).max())
+
+    if rank == 0:
+        bpp = N.PIXEL_BYTES[pixel]
+        src_px = n * sw * sh
+        total_px = src_px * world * args.steps
+        read_b = n * sw * sh * bpp
+        write_b = n * dw * dh * bpp
+        alg_bytes = read_b + write_b
+        ach = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "Mpix/s batched 4K->1080p rgba cubic resize" if args.workload.startswith("cfg2") else "Mpix/s " + args.workload,
+            "value": round(total_px / elapsed / 1e6, 1),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "%s: %d x %dx%d %s -> %dx%d per GPU, opts %s (picha default = cubic, filterScale 0.70), source pixels counted"
+                            % (args.workload, n, sw, sh, pixel, dw, dh, json.dumps(opts)),
+                "images_per_gpu": n,
+                "kernel": kernel,
+                "parallelism": "image-sharded x%d" % world,
+                "dst_mpix_per_s": round(n * dw * dh * world * args.steps / elapsed / 1e6, 1),
+                "parity_max_code_diff_vs_oracle_image0": parity,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": round(ach, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(ach / HBM_PEAK_GBS, 4),
+                "traffic": traffic,
+                "kernel": kernel,
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": round(avg_launch_ms, 4),
+                "read_only_frac": round(read_b / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.workload)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -56,6 +57,8 @@ bool valid_pixel(int p) { return p >= 0 && p < PICHA_NUM_PIXELS; }
 std::mutex g_opt_mu;
 long g_opt_path = 0;        // 0 auto, 1 two-pass, 2 fused (error if unsupported)
 long g_opt_row_chunks = 0;  // 0 auto
+long g_opt_numerics = 0;    // 0 reference arithmetic (bit-exact), 1 fused-multiply-add flavour (<= 1 code value)
+long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 
 // ---- per-device state ---------------------------------------------------------------------------
 struct DeviceAxis {
@@ -64,9 +67,15 @@ struct DeviceAxis {
     // generic (two-pass) tables
     int32_t *left = nullptr, *count = nullptr, *eff = nullptr;
     float *weight = nullptr;  // [dst][taps]
-    // fused, x role
-    int32_t *x_left = nullptr;  // shifted so x_left + taps <= src
-    float *x_weight = nullptr;  // [taps][dst]
+    // fused, x role: built on demand per (outputs per lane, step, kernel taps, numerics, sample type)
+    struct XTable {
+        bool ok = false;        // false: the tap table does not have this uniform structure
+        void *blob = nullptr;
+        int32_t *left = nullptr;  // [groups]
+        float *weight = nullptr;  // [taps][stride]
+        int groups = 0, stride = 0;
+    };
+    std::map<std::tuple<int, int, int, int, int>, XTable> xtables;
     // fused, y role
     int4 *y_info = nullptr;
     float *y_weight = nullptr;  // [dst][y_pad]
@@ -151,7 +160,7 @@ int temp_release(TempBuf &t, hipStream_t s) {
 
 // Builds (once) and uploads the tables for one axis.  Synchronous on first use of a geometry;
 // afterwards a pure lookup.
-int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, const DeviceAxis **out) {
+int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, DeviceAxis **out) {
     uint32_t bits;
     memcpy(&bits, &fscale, 4);
     AxisKey key(filter, bits, src, dst);
@@ -170,16 +179,6 @@ int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, const D
     ax->y_pad = YP;
 
     // host-side images of the device tables
-    std::vector<int32_t> x_left(dst);
-    std::vector<float> x_weight((size_t)T * dst, 0.0f);
-    for (int i = 0; i < dst; ++i) {
-        // keep every tap address in range with a fixed tap count: shift the window left and pad
-        // zeros in FRONT (0 * finite sample contributes +-0 and leaves the sum unchanged)
-        int l = t.left[i], shift = 0;
-        if (l + T > src) { shift = l + T - src; l = src - T; }
-        x_left[i] = l;
-        for (int j = 0; j < t.count[i]; ++j) x_weight[(size_t)(j + shift) * dst + i] = t.weight[(size_t)i * T + j];
-    }
     std::vector<int4> y_info(dst);
     std::vector<float> y_weight((size_t)dst * YP, 0.0f);
     std::vector<int32_t> y_slot((size_t)dst * YP, 0);
@@ -199,8 +198,6 @@ int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, const D
         {t.count.data(), sizeof(int32_t) * dst, (void **)&ax->count},
         {t.eff.data(), sizeof(int32_t) * (size_t)dst * T, (void **)&ax->eff},
         {t.weight.data(), sizeof(float) * (size_t)dst * T, (void **)&ax->weight},
-        {x_left.data(), sizeof(int32_t) * dst, (void **)&ax->x_left},
-        {x_weight.data(), sizeof(float) * (size_t)dst * T, (void **)&ax->x_weight},
         {y_info.data(), sizeof(int4) * dst, (void **)&ax->y_info},
         {y_weight.data(), sizeof(float) * (size_t)dst * YP, (void **)&ax->y_weight},
         {y_slot.data(), sizeof(int32_t) * (size_t)dst * YP, (void **)&ax->y_slot},
@@ -218,6 +215,59 @@ int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, const D
     HIP_TRY(hipMemcpy(ax->blob, image.data(), total, hipMemcpyHostToDevice));
     *out = ax.get();
     ctx->axes[key] = std::move(ax);
+    return PICHA_OK;
+}
+
+// Horizontal tables for the fused kernel: `per_lane` consecutive outputs share one lane; output q of
+// a group reads span pixels [step*q, step*q + taps) of the span starting at left[group].  For
+// per_lane > 1 this needs the reference's tap table to have that uniform stride (true for integer
+// scale factors); the check below decides, the result is cached.  Taps are zero padded to `taps`;
+// pixels a padded tap addresses are either inside the image (finite, times 0) or outside it (the
+// kernel's buffer loads return 0).  fma: weights pre-multiplied by 1/max of the sample type.
+int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps, int fma, int is16,
+               const DeviceAxis::XTable **out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto key = std::make_tuple(per_lane, step, taps, fma, is16);
+    auto it = ax->xtables.find(key);
+    if (it != ax->xtables.end()) { *out = &it->second; return PICHA_OK; }
+    DeviceAxis::XTable xt;
+    const AxisTaps &t = ax->host;
+    const int dst = t.dst_size, T = t.taps;
+    const int groups = (dst + per_lane - 1) / per_lane;
+    const int stride = groups * per_lane;
+    std::vector<int32_t> left(groups);
+    std::vector<float> weight((size_t)taps * stride, 0.0f);
+    const float inv = is16 ? 1.0f / 65535.0f : 1.0f / 255.0f;
+    bool ok = taps >= T || per_lane > 1;
+    for (int g = 0; g < groups && ok; ++g) {
+        int base = INT32_MAX;
+        for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) base = std::min(base, t.left[g * per_lane + q] - step * q);
+        left[g] = base;
+        for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) {
+            const int i = g * per_lane + q;
+            const int first = t.left[i] - (base + step * q);  // >= 0 by construction
+            if (first + t.count[i] > taps) { ok = false; break; }
+            for (int j = 0; j < t.count[i]; ++j) {
+                const float w = t.weight[(size_t)i * T + j];
+                weight[(size_t)(first + j) * stride + i] = fma ? w * inv : w;
+            }
+        }
+    }
+    xt.ok = ok;
+    if (ok) {
+        const size_t lb = align_up(sizeof(int32_t) * groups, 256), wb = sizeof(float) * weight.size();
+        std::vector<uint8_t> image(lb + wb, 0);
+        memcpy(image.data(), left.data(), sizeof(int32_t) * groups);
+        memcpy(image.data() + lb, weight.data(), wb);
+        HIP_TRY(hipMalloc(&xt.blob, lb + wb));
+        HIP_TRY(hipMemcpy(xt.blob, image.data(), lb + wb, hipMemcpyHostToDevice));
+        xt.left = static_cast<int32_t *>(xt.blob);
+        xt.weight = reinterpret_cast<float *>(static_cast<uint8_t *>(xt.blob) + lb);
+        xt.groups = groups;
+        xt.stride = stride;
+    }
+    auto ins = ax->xtables.emplace(key, xt);
+    *out = &ins.first->second;
     return PICHA_OK;
 }
 
@@ -288,21 +338,53 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                  float fscale, hipStream_t s) {
     const picha_image &s0 = src[0], &d0 = dst[0];
     const int pixel = s0.pixel;
-    const DeviceAxis *ax = nullptr, *ay = nullptr;
+    DeviceAxis *ax = nullptr, *ay = nullptr;
     int rc = get_axis(ctx, filter, fscale, s0.width, d0.width, &ax);
     if (rc) return rc;
     rc = get_axis(ctx, filter, fscale, s0.height, d0.height, &ay);
     if (rc) return rc;
 
-    long opt_path, opt_chunks;
-    { std::lock_guard<std::mutex> lk(g_opt_mu); opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; }
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane;
+    {
+        std::lock_guard<std::mutex> lk(g_opt_mu);
+        opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
+    }
+    const int fma = opt_numerics == 1 ? 1 : 0;
+    const int is16 = pixel >= PICHA_R16;
 
+    // ---- pick the fused configuration: multi-output lanes where the table is uniform, else 1 per lane
     const int ring = std::max(ay->host.span, 1);
-    bool fused_ok = fused_supported(pixel, ax->host.taps, ay->host.taps, ring);
+    const size_t src_span = image_span(s0), dst_span = image_span(d0);
+    bool fused_ok = src_span < (1u << 31) && dst_span < (1u << 31);
     const int al = fused_align(pixel);
     for (int i = 0; i < n && fused_ok; ++i) {
         if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) fused_ok = false;
         if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % al) fused_ok = false;
+    }
+    int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps);
+    const DeviceAxis::XTable *xt = nullptr;
+    if (fused_ok && opt_per_lane != 1) {
+        // integer decimation / interpolation step of the tap windows
+        const int st = std::max(1, (int)std::lround((double)s0.width / d0.width));
+        static const int cand[] = {2, 4};
+        for (int pl : cand) {
+            if (opt_per_lane > 1 && pl != opt_per_lane) continue;
+            if (opt_per_lane == 0 && pl != 2) continue;  // default: 2 outputs per lane
+            if (!fused_multi_supported(pixel, pl, st, ax->host.taps)) continue;
+            if (!fused_supported(pixel, ax->host.taps, ay->host.taps, ring, pl)) continue;
+            const DeviceAxis::XTable *cx = nullptr;
+            rc = get_xtable(ctx, ax, pl, st, ax->host.taps, fma, is16, &cx);
+            if (rc) return rc;
+            if (cx->ok) { xt = cx; per_lane = pl; step = st; ktaps = ax->host.taps; break; }
+        }
+    }
+    if (fused_ok && !xt) {
+        fused_ok = ktaps > 0 && fused_supported(pixel, ktaps, ay->host.taps, ring, 1);
+        if (fused_ok) {
+            rc = get_xtable(ctx, ax, 1, 1, ktaps, fma, is16, &xt);
+            if (rc) return rc;
+            fused_ok = xt->ok;
+        }
     }
     if (opt_path == 2 && !fused_ok) return fail(PICHA_ERR_ARGUMENT, "fused kernel forced but unsupported for this geometry");
     const bool use_fused = fused_ok && opt_path != 1;
@@ -326,13 +408,16 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         }
         p.src_stride = s0.stride; p.dst_stride = d0.stride;
         p.src_w = s0.width; p.src_h = s0.height; p.dst_w = d0.width; p.dst_h = d0.height;
+        p.src_bytes = (unsigned)src_span; p.dst_bytes = (unsigned)dst_span;
         p.n_images = n;
-        p.x_left = ax->x_left; p.x_weight = ax->x_weight; p.x_taps = ax->host.taps;
+        p.x_left = xt->left; p.x_weight = xt->weight; p.x_taps = ktaps;
+        p.x_per_lane = per_lane; p.x_step = step; p.x_groups = xt->groups; p.xw_stride = xt->stride;
+        p.fma = fma;
         p.y_info = ay->y_info; p.y_weight = ay->y_weight; p.y_slot = ay->y_slot;
         p.y_taps = ay->host.taps; p.y_pad = ay->y_pad;
         p.ring_slots = ring;
         // row chunks: enough waves to fill 256 CUs several times over, chunks not too short
-        const long long col_waves = (d0.width + 63) / 64;
+        const long long col_waves = (xt->groups + 63) / 64;
         long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
         chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
         p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
@@ -641,6 +726,8 @@ int picha_hip_set_option(const char *key, long value) {
     std::lock_guard<std::mutex> lk(g_opt_mu);
     if (strcmp(key, "path") == 0) { g_opt_path = value; return PICHA_OK; }
     if (strcmp(key, "row_chunks") == 0) { g_opt_row_chunks = value; return PICHA_OK; }
+    if (strcmp(key, "numerics") == 0) { g_opt_numerics = value; return PICHA_OK; }
+    if (strcmp(key, "per_lane") == 0) { g_opt_per_lane = value; return PICHA_OK; }
     return fail(PICHA_ERR_ARGUMENT, "unknown option %s", key);
 }
 long picha_hip_get_option(const char *key) {
@@ -648,6 +735,8 @@ long picha_hip_get_option(const char *key) {
     std::lock_guard<std::mutex> lk(g_opt_mu);
     if (strcmp(key, "path") == 0) return g_opt_path;
     if (strcmp(key, "row_chunks") == 0) return g_opt_row_chunks;
+    if (strcmp(key, "numerics") == 0) return g_opt_numerics;
+    if (strcmp(key, "per_lane") == 0) return g_opt_per_lane;
     return -1;
 }
 

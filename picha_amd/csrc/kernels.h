@@ -52,10 +52,17 @@ struct FusedParams {
     void *const *dst_tab;
     int src_stride, dst_stride;
     int src_w, src_h, dst_w, dst_h;
+    unsigned src_bytes, dst_bytes;  // bytes of ONE image (buffer descriptor range)
     int n_images;
-    const int32_t *x_left;   // [dst_w], shifted so that x_left + x_taps <= src_w
-    const float *x_weight;   // tap-major [x_taps][dst_w], zero padded (front-padded where shifted)
-    int x_taps;
+    // x axis: a lane owns x_per_lane consecutive outputs ("group"); output q of a group uses the
+    // span pixels [x_step*q, x_step*q + x_taps) of the span that starts at x_left[group]
+    const int32_t *x_left;   // [x_groups] first source pixel of the group's span (may be < 0)
+    const float *x_weight;   // tap-major [x_taps][xw_stride], zero padded
+    int x_taps;              // kernel tap count (bucket >= table taps)
+    int x_per_lane, x_step;
+    int x_groups, xw_stride;
+    int fma;                 // 0: reference arithmetic; 1: fused multiply-add flavour (weights pre-scaled)
+    // y axis
     const int4 *y_info;      // [dst_h] {left, need, count, 0}
     const float *y_weight;   // [dst_h][y_pad] zero padded
     const int32_t *y_slot;   // [dst_h][y_pad] ring slot (eff % ring_slots); padded taps repeat tap 0
@@ -64,8 +71,10 @@ struct FusedParams {
     int rows_per_chunk, n_chunks;
 };
 // True if a fused instantiation exists for this format / tap counts and its LDS ring fits.
-bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots);
-// Padded row length of the y tables the fused kernel for y_taps expects (8, 16 or 32).
+bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots, int per_lane);
+bool fused_multi_supported(int pixel, int per_lane, int step, int x_taps);
+// Kernel tap count for a table with x_taps taps (0: none).  Padded row length of the y tables.
+int fused_x_bucket(int x_taps);
 int fused_y_pad(int y_taps);
 hipError_t launch_resize_fused(int pixel, const FusedParams &p, hipStream_t s, const char **kernel_name);
 

@@ -14,6 +14,7 @@
 #include "kernels.h"
 
 #include <algorithm>
+#include <cstdio>
 
 #pragma clang fp contract(off)
 
@@ -264,126 +265,208 @@ hipError_t launch_twopass_t(const TwoPassParams &p, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------
-// Fused resize kernel.
+// Fused resize kernel ("span" kernel).
 //
-// Work decomposition: one WAVE owns 64 adjacent output columns of one row-chunk of one image and
-// marches down the source rows that chunk needs.  A workgroup is four such waves (256 adjacent
-// output columns -> the workgroup streams a contiguous span of every source row).  There is no
-// cross-lane or cross-wave data flow and therefore no barrier anywhere:
-//   * lane x keeps its TX horizontal weights in VGPRs for the whole march;
-//   * each source row is resampled horizontally into one value per lane (all channels) and
-//     written to that lane's cell of a per-wave LDS ring of `ring_slots` rows — the GPU analogue
-//     of the reference's FloatBuffer ring (src/resize.cc:52-64,83);
-//   * when the last row an output row needs has been resampled, the vertical taps (wave-uniform,
-//     read through scalar loads) combine ring rows and the packed pixel is stored.
-// Source reads are software-prefetched D rows ahead in registers.
+// Work decomposition: one WAVE owns 64*P adjacent output columns of one row-chunk of one image
+// and marches down the source rows that chunk needs; a workgroup is four such waves (256*P
+// adjacent output columns, so it streams one contiguous piece of every source row).  No data
+// ever crosses lanes or waves, hence no barrier anywhere:
+//   * a lane owns P consecutive output columns.  Per source row it loads ONE contiguous span of
+//     S*(P-1)+TX source pixels (the union of its outputs' tap windows; output p's window starts
+//     S*p pixels into the span — for P > 1 the host has verified that the tap table has this
+//     uniform stride), converts every pixel of the span to float ONCE and applies its P*TX
+//     lane-resident weights.  Loads are buffer loads against a descriptor of exactly the image's
+//     bytes, so taps that hang over an image edge (they always carry weight 0) read as 0.
+//   * the P resampled values go to the lane's cells of a per-wave LDS ring of `ring_slots` rows —
+//     the GPU analogue of the reference's FloatBuffer ring (src/resize.cc:52-64,83);
+//   * when the last source row an output row needs has been resampled, the vertical taps (slots
+//     through scalar loads, weights broadcast into VGPRs) combine ring rows; the packed pixels
+//     are stored with one buffer store per lane.
+// Source rows are software-prefetched D rows ahead in registers.
+//
+// Numerics: FMA == false is the reference arithmetic (unfused, bit-exact with the CPU path);
+// FMA == true fuses multiply-adds, folds the 1/max unpack scale into the horizontal weights and
+// rounds to nearest on pack — results differ from the reference by at most one code value.
 // ---------------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(4))) int32_t *const_i32_ptr;  // forces scalar (SMEM) loads
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
 template <int CH> struct RingSlot { using type = float4; static constexpr int kFloats = 4; };
 template <> struct RingSlot<1> { using type = float; static constexpr int kFloats = 1; };
 template <> struct RingSlot<2> { using type = float2; static constexpr int kFloats = 2; };
 
-// raw pixel as loaded (one tap): number of 32-bit registers
-template <int CH, bool S16> struct RawPx {
-    static constexpr int BPP = CH * Sample<S16>::kBytes;
-    static constexpr int kRegs = (BPP == 8) ? 2 : (CH == 3 ? 3 : 1);
+template <int CH, bool S16, int P, int S, int TX> struct SpanCfg {
+    static constexpr int BPS = Sample<S16>::kBytes;
+    static constexpr int BPP = CH * BPS;
+    static constexpr int SPAN = S * (P - 1) + TX;       // source pixels a lane reads per row
+    static constexpr bool WORDS = (BPP % 4 == 0);       // span loadable as whole dwords
+    static constexpr int PXREGS = WORDS ? BPP / 4 : (CH == 3 ? 3 : 1);
+    static constexpr int NW = SPAN * PXREGS;            // raw registers per row
+    static constexpr int D = NW <= 8 ? 4 : (NW <= 16 ? 3 : (NW <= 32 ? 2 : 1));  // prefetch depth
+    static_assert(WORDS || P == 1, "multi-output lanes need dword-sized pixels");
 };
 
-template <int CH, bool S16>
-__device__ __forceinline__ void load_px(const uint8_t *p, uint32_t *r) {
-    constexpr int BPP = RawPx<CH, S16>::BPP;
-    if constexpr (BPP == 1) r[0] = *p;
-    else if constexpr (BPP == 2) r[0] = *reinterpret_cast<const uint16_t *>(p);
-    else if constexpr (BPP == 4) r[0] = *reinterpret_cast<const uint32_t *>(p);
-    else if constexpr (BPP == 8) { uint2 v = *reinterpret_cast<const uint2 *>(p); r[0] = v.x; r[1] = v.y; }
-    else if constexpr (BPP == 3) { r[0] = p[0]; r[1] = p[1]; r[2] = p[2]; }
-    else { const uint16_t *q = reinterpret_cast<const uint16_t *>(p); r[0] = q[0]; r[1] = q[1]; r[2] = q[2]; }  // BPP 6
-}
-
-template <int CH, bool S16>
-__device__ __forceinline__ void unpack_px(const uint32_t *r, float *u) {
-    constexpr int BPP = RawPx<CH, S16>::BPP;
-    if constexpr (CH == 3) {
-        u[0] = unpack_sample<S16>(r[0]); u[1] = unpack_sample<S16>(r[1]); u[2] = unpack_sample<S16>(r[2]);
-    } else if constexpr (BPP == 1 || (BPP == 2 && S16)) {
-        u[0] = unpack_sample<S16>(r[0]);
-    } else if constexpr (BPP == 2) {  // greya
-        u[0] = unpack_sample<false>(r[0] & 0xffu); u[1] = unpack_sample<false>(r[0] >> 8);
-    } else if constexpr (BPP == 4 && !S16) {  // rgba
-        u[0] = unpack_sample<false>(r[0] & 0xffu); u[1] = unpack_sample<false>((r[0] >> 8) & 0xffu);
-        u[2] = unpack_sample<false>((r[0] >> 16) & 0xffu); u[3] = unpack_sample<false>(r[0] >> 24);
-    } else if constexpr (BPP == 4) {  // r16g16
-        u[0] = unpack_sample<true>(r[0] & 0xffffu); u[1] = unpack_sample<true>(r[0] >> 16);
-    } else {  // r16g16b16a16
-        u[0] = unpack_sample<true>(r[0] & 0xffffu); u[1] = unpack_sample<true>(r[0] >> 16);
-        u[2] = unpack_sample<true>(r[1] & 0xffffu); u[3] = unpack_sample<true>(r[1] >> 16);
-    }
-}
-
-template <int CH, bool S16>
-__device__ __forceinline__ void pack_store_px(uint8_t *p, const float *v) {
-    constexpr int BPP = RawPx<CH, S16>::BPP;
-    uint32_t q[CH];
+// `careful` (wave-uniform): some lane's span starts before the image (negative offset; only possible
+// in row 0 for the left-most lane group of multi-output lanes).  A wrapped 32-bit offset would put
+// the WHOLE merged multi-dword load out of range, so those dwords are clamped one by one instead
+// (they only ever meet zero weights).
+template <typename C>
+__device__ __forceinline__ void load_span(__amdgpu_buffer_rsrc_t rsrc, int32_t off, uint32_t *raw, bool careful) {
+    const uint32_t voff = uint32_t(off);
+    if constexpr (C::WORDS) {
+        if (careful) {
 #pragma unroll
-    for (int c = 0; c < CH; ++c) q[c] = pack_sample<S16>(v[c]);
-    if constexpr (BPP == 1) *p = uint8_t(q[0]);
-    else if constexpr (BPP == 2 && S16) *reinterpret_cast<uint16_t *>(p) = uint16_t(q[0]);
-    else if constexpr (BPP == 2) *reinterpret_cast<uint16_t *>(p) = uint16_t(q[0] | (q[1] << 8));
-    else if constexpr (BPP == 3) { p[0] = uint8_t(q[0]); p[1] = uint8_t(q[1]); p[2] = uint8_t(q[2]); }
-    else if constexpr (BPP == 4 && !S16) *reinterpret_cast<uint32_t *>(p) = q[0] | (q[1] << 8) | (q[2] << 16) | (q[3] << 24);
-    else if constexpr (BPP == 4) *reinterpret_cast<uint32_t *>(p) = q[0] | (q[1] << 16);
-    else if constexpr (BPP == 6) {
-        uint16_t *o = reinterpret_cast<uint16_t *>(p);
-        o[0] = uint16_t(q[0]); o[1] = uint16_t(q[1]); o[2] = uint16_t(q[2]);
-    } else {
-        uint2 o; o.x = q[0] | (q[1] << 16); o.y = q[2] | (q[3] << 16);
-        *reinterpret_cast<uint2 *>(p) = o;
+            for (int i = 0; i < C::NW; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, uint32_t(max(off + 4 * i, 0)), 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < C::NW; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff + 4 * i, 0, 0);
+        }
+    } else if constexpr (C::BPP == 1) {
+#pragma unroll
+        for (int i = 0; i < C::SPAN; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, voff + i, 0, 0);
+    } else if constexpr (C::BPP == 2) {
+#pragma unroll
+        for (int i = 0; i < C::SPAN; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff + 2 * i, 0, 0);
+    } else if constexpr (C::BPP == 3) {
+#pragma unroll
+        for (int i = 0; i < C::SPAN * 3; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b8(rsrc, voff + i, 0, 0);
+    } else {  // 6 bytes: three u16
+#pragma unroll
+        for (int i = 0; i < C::SPAN * 3; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b16(rsrc, voff + 2 * i, 0, 0);
     }
 }
 
-template <int CH, bool S16, int TX, int TYB, int D>
-__global__ __launch_bounds__(256) void resize_fused_kernel(FusedParams p) {
-    constexpr int BPP = RawPx<CH, S16>::BPP;
-    constexpr int NR = RawPx<CH, S16>::kRegs;
+// float value(s) of span pixel q; SCALE = multiply by 1/max (reference unpack) or leave the integer value
+template <typename C, int CH, bool S16, bool SCALE>
+__device__ __forceinline__ void unpack_span_px(const uint32_t *raw, int q, float *u) {
+    uint32_t s[CH];
+    if constexpr (CH == 3) { s[0] = raw[3 * q]; s[1] = raw[3 * q + 1]; s[2] = raw[3 * q + 2]; }
+    else if constexpr (C::BPP == 1 || (C::BPP == 2 && S16)) { s[0] = raw[q]; }
+    else if constexpr (C::BPP == 2) { s[0] = raw[q] & 0xffu; s[1] = raw[q] >> 8; }
+    else if constexpr (C::BPP == 4 && !S16) {
+        s[0] = raw[q] & 0xffu; s[1] = (raw[q] >> 8) & 0xffu; s[2] = (raw[q] >> 16) & 0xffu; s[3] = raw[q] >> 24;
+    } else if constexpr (C::BPP == 4) { s[0] = raw[q] & 0xffffu; s[1] = raw[q] >> 16; }
+    else { s[0] = raw[2 * q] & 0xffffu; s[1] = raw[2 * q] >> 16; s[2] = raw[2 * q + 1] & 0xffffu; s[3] = raw[2 * q + 1] >> 16; }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) u[c] = SCALE ? unpack_sample<S16>(s[c]) : float(s[c]);
+}
+
+// pack CH floats into the little-endian bytes of one pixel, returned in up to two dwords
+template <int CH, bool S16, bool FMA>
+__device__ __forceinline__ void pack_px_words(const float *v, uint32_t *w) {
+    if constexpr (FMA && !S16) {
+        // round-to-nearest-even + saturate in one instruction per channel
+        uint32_t r = 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) r = __builtin_amdgcn_cvt_pk_u8_f32(v[c] * 255.0f, c, r);
+        w[0] = r;
+    } else if constexpr (FMA && S16) {
+        // v_cvt_pknorm_u16_f32: saturating round(v * 65535) for two channels at once
+#pragma unroll
+        for (int c = 0; c < CH; c += 2) {
+            auto pr = __builtin_amdgcn_cvt_pknorm_u16(v[c], (c + 1 < CH) ? v[c + 1] : 0.0f);
+            w[c / 2] = uint32_t(pr[0]) | (uint32_t(pr[1]) << 16);
+        }
+    } else {
+        uint32_t q[CH];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) q[c] = pack_sample<S16>(v[c]);
+        if constexpr (!S16) {
+            w[0] = q[0];
+            if constexpr (CH >= 2) w[0] |= q[1] << 8;
+            if constexpr (CH >= 3) w[0] |= q[2] << 16;
+            if constexpr (CH >= 4) w[0] |= q[3] << 24;
+        } else {
+            w[0] = q[0];
+            if constexpr (CH >= 2) w[0] |= q[1] << 16;
+            if constexpr (CH >= 3) w[1] = q[2];
+            if constexpr (CH >= 4) w[1] |= q[3] << 16;
+        }
+    }
+}
+
+template <int CH, bool S16>
+__device__ __forceinline__ void store_px_words(__amdgpu_buffer_rsrc_t rsrc, uint32_t off, const uint32_t *w) {
+    constexpr int BPP = CH * Sample<S16>::kBytes;
+    if constexpr (BPP == 1) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)w[0], rsrc, off, 0, 0);
+    else if constexpr (BPP == 2) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w[0], rsrc, off, 0, 0);
+    else if constexpr (BPP == 3) {
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)w[0], rsrc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(w[0] >> 8), rsrc, off + 1, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)(w[0] >> 16), rsrc, off + 2, 0, 0);
+    } else if constexpr (BPP == 4) __builtin_amdgcn_raw_buffer_store_b32(w[0], rsrc, off, 0, 0);
+    else if constexpr (BPP == 6) {
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w[0], rsrc, off, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(w[0] >> 16), rsrc, off + 2, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w[1], rsrc, off + 4, 0, 0);
+    } else {
+        u32x2 o = {w[0], w[1]};
+        __builtin_amdgcn_raw_buffer_store_b64(o, rsrc, off, 0, 0);
+    }
+}
+
+template <int CH, bool S16, int P, int S, int TX, int TYB, bool FMA>
+__global__ __launch_bounds__(256) void resize_span_kernel(FusedParams p) {
+    using C = SpanCfg<CH, S16, P, S, TX>;
     using Slot = typename RingSlot<CH>::type;
     constexpr int SF = RingSlot<CH>::kFloats;
+    constexpr int D = C::D;
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
 
     const int lane = threadIdx.x & (kWave - 1);
-    const int wave = threadIdx.x >> 6;
-    const int col0 = (blockIdx.x * 4 + wave) * kWave;
-    if (col0 >= p.dst_w) return;  // wave-uniform: this wave has no columns (no barriers in this kernel)
-    const int x = col0 + lane;
-    const bool active = x < p.dst_w;
-    const int xc = active ? x : p.dst_w - 1;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp0 = (blockIdx.x * 4 + wave) * kWave;  // first lane-group of this wave
+    if (grp0 * P >= p.dst_w) return;  // wave-uniform: no columns for this wave (kernel has no barriers)
+    const int grp = min(grp0 + lane, p.x_groups - 1);  // surplus lanes duplicate the last group, never store
+    const int x0 = (grp0 + lane) * P;                  // first output column of this lane
 
     const int img = blockIdx.z;
     const uint8_t *sbase = p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch;
     uint8_t *dbase = p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch;
+    // descriptors cover exactly one image: anything outside reads 0 / is not written
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(sbase), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t yw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.y_weight), 0, p.dst_h * p.y_pad * 4, 0x00020000);
 
     const int y0 = blockIdx.y * p.rows_per_chunk;
     const int y1 = min(p.dst_h, y0 + p.rows_per_chunk);
     if (y0 >= y1) return;
 
-    // lane-resident horizontal taps
-    float wx[TX];
+    // lane-resident horizontal taps: wx[p][j] multiplies span pixel S*p + j
+    float wx[P][TX];
 #pragma unroll
-    for (int j = 0; j < TX; ++j) wx[j] = p.x_weight[(size_t)j * p.dst_w + xc];
-    const uint32_t xoff = uint32_t(p.x_left[xc]) * BPP;
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int j = 0; j < TX; ++j) wx[q][j] = p.x_weight[(size_t)j * p.xw_stride + grp * P + q];
+    const int32_t lane_off = p.x_left[grp] * C::BPP;  // may be negative at the left edge (zero-weight taps)
+    const bool edge_wave = P > 1 && __any(lane_off < 0);
 
-    Slot *ring = reinterpret_cast<Slot *>(lds_raw) + (size_t)wave * p.ring_slots * kWave + lane;
+    Slot *ring = reinterpret_cast<Slot *>(lds_raw) + (size_t)wave * p.ring_slots * (kWave * P) + lane;
 
-    const int r0 = p.y_info[y0].x;       // first source row this chunk touches
-    const int r1 = p.y_info[y1 - 1].y;   // last
+    const_i32_ptr yinfo = (const_i32_ptr)(p.y_info);  // int4 {left, need, count, 0} per output row
+    const_i32_ptr yslot = (const_i32_ptr)(p.y_slot);
+    const int r0 = yinfo[4 * y0];            // first source row this chunk touches
+    const int r1 = yinfo[4 * (y1 - 1) + 1];  // last
     int slot = r0 % p.ring_slots;
     int y = y0;
-    int cur_need = p.y_info[y0].y;
+    int cur_need = yinfo[4 * y0 + 1];
+    int cur_cnt = yinfo[4 * y0 + 2];
 
-    uint32_t raw[D][TX][NR];
+    // vertical weights of the pending output row, broadcast into VGPRs (an SGPR operand would halve
+    // the VALU rate of every multiply that uses it)
+    float wv[TYB];
+    auto load_wv = [&](int yy) {
+#pragma unroll
+        for (int j = 0; j < TYB; ++j) wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yw_rs, (uint32_t)(yy * p.y_pad + j) * 4u, 0, 0));
+    };
+    load_wv(y0);
+
+    uint32_t raw[D][C::NW];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        const uint8_t *row = sbase + (long long)min(r0 + d, r1) * p.src_stride;
-#pragma unroll
-        for (int j = 0; j < TX; ++j) load_px<CH, S16>(row + xoff + j * BPP, raw[d][j]);
+        const int rr = min(r0 + d, r1);
+        load_span<C>(src_rs, rr * p.src_stride + lane_off, raw[d], edge_wave && rr == 0);
     }
 
     for (int r = r0; r <= r1;) {
@@ -391,49 +474,91 @@ __global__ __launch_bounds__(256) void resize_fused_kernel(FusedParams p) {
         for (int d = 0; d < D; ++d) {
             if (r <= r1) {
                 // ---- horizontal pass of source row r (src/resize.cc:110-117) ----
-                float acc[SF];
+                float acc[P][SF];
 #pragma unroll
-                for (int j = 0; j < TX; ++j) {
+                for (int q = 0; q < C::SPAN; ++q) {
                     float u[CH];
-                    unpack_px<CH, S16>(raw[d][j], u);
+                    unpack_span_px<C, CH, S16, !FMA>(raw[d], q, u);
 #pragma unroll
-                    for (int c = 0; c < CH; ++c) acc[c] = (j == 0) ? wx[0] * u[c] : acc[c] + wx[j] * u[c];
+                    for (int o = 0; o < P; ++o) {
+                        const int j = q - S * o;  // tap index of span pixel q for output o
+                        if (j >= 0 && j < TX) {
+#pragma unroll
+                            for (int c = 0; c < CH; ++c) {
+                                if (j == 0) acc[o][c] = wx[o][0] * u[c];
+                                else if constexpr (FMA) acc[o][c] = __builtin_fmaf(wx[o][j], u[c], acc[o][c]);
+                                else acc[o][c] = acc[o][c] + wx[o][j] * u[c];
+                            }
+                        }
+                    }
                 }
-                if constexpr (CH == 3) acc[3] = 0.0f;
                 // refill the prefetch slot with row r + D
                 {
-                    const uint8_t *row = sbase + (long long)min(r + D, r1) * p.src_stride;
-#pragma unroll
-                    for (int j = 0; j < TX; ++j) load_px<CH, S16>(row + xoff + j * BPP, raw[d][j]);
+                    const int rr = min(r + D, r1);
+                    load_span<C>(src_rs, rr * p.src_stride + lane_off, raw[d], edge_wave && rr == 0);
                 }
-                Slot sv;
-                if constexpr (SF == 1) sv = acc[0];
-                else if constexpr (SF == 2) { sv.x = acc[0]; sv.y = acc[1]; }
-                else { sv.x = acc[0]; sv.y = acc[1]; sv.z = acc[2]; sv.w = acc[3]; }
-                ring[slot * kWave] = sv;
+#pragma unroll
+                for (int o = 0; o < P; ++o) {
+                    Slot sv;
+                    if constexpr (SF == 1) sv = acc[o][0];
+                    else if constexpr (SF == 2) { sv.x = acc[o][0]; sv.y = acc[o][1]; }
+                    else { sv.x = acc[o][0]; sv.y = acc[o][1]; sv.z = acc[o][2]; sv.w = (CH == 4) ? acc[o][3] : 0.0f; }
+                    ring[(slot * P + o) * kWave] = sv;
+                }
                 slot = (slot + 1 == p.ring_slots) ? 0 : slot + 1;
 
                 // ---- vertical pass for every output row completed by row r (src/resize.cc:122-132) ----
                 while (cur_need <= r) {
-                    const int cnt = p.y_info[y].z;
-                    const float *wy = p.y_weight + (size_t)y * p.y_pad;
-                    const int32_t *sy = p.y_slot + (size_t)y * p.y_pad;
-                    float o[SF];
+                    const_i32_ptr sy = yslot + (size_t)y * p.y_pad;
+                    float o[P][SF];
 #pragma unroll
                     for (int j = 0; j < TYB; ++j) {
-                        if (j >= cnt) break;
-                        const Slot v = ring[sy[j] * kWave];
-                        const float w = wy[j];
-                        float vf[SF];
-                        if constexpr (SF == 1) vf[0] = v;
-                        else if constexpr (SF == 2) { vf[0] = v.x; vf[1] = v.y; }
-                        else { vf[0] = v.x; vf[1] = v.y; vf[2] = v.z; vf[3] = v.w; }
+                        if (j >= cur_cnt) break;
+                        const int sj = sy[j];
 #pragma unroll
-                        for (int c = 0; c < CH; ++c) o[c] = (j == 0) ? w * vf[c] : o[c] + w * vf[c];
+                        for (int q = 0; q < P; ++q) {
+                            const Slot v = ring[(sj * P + q) * kWave];
+                            float vf[SF];
+                            if constexpr (SF == 1) vf[0] = v;
+                            else if constexpr (SF == 2) { vf[0] = v.x; vf[1] = v.y; }
+                            else { vf[0] = v.x; vf[1] = v.y; vf[2] = v.z; vf[3] = v.w; }
+#pragma unroll
+                            for (int c = 0; c < CH; ++c) {
+                                if (j == 0) o[q][c] = wv[0] * vf[c];
+                                else if constexpr (FMA) o[q][c] = __builtin_fmaf(wv[j], vf[c], o[q][c]);
+                                else o[q][c] = o[q][c] + wv[j] * vf[c];
+                            }
+                        }
                     }
-                    if (active) pack_store_px<CH, S16>(dbase + (long long)y * p.dst_stride + (long long)x * BPP, o);
+                    // pack + store this lane's P pixels of output row y
+                    const uint32_t doff = uint32_t(y * p.dst_stride + x0 * C::BPP);
+                    uint32_t pw[P][2];
+#pragma unroll
+                    for (int q = 0; q < P; ++q) pack_px_words<CH, S16, FMA>(o[q], pw[q]);
+                    if constexpr (P == 2 && C::BPP == 4) {
+                        if (x0 + 1 < p.dst_w) { u32x2 t = {pw[0][0], pw[1][0]}; __builtin_amdgcn_raw_buffer_store_b64(t, dst_rs, doff, 0, 0); }
+                        else if (x0 < p.dst_w) __builtin_amdgcn_raw_buffer_store_b32(pw[0][0], dst_rs, doff, 0, 0);
+                    } else if constexpr (P == 4 && C::BPP == 4) {
+                        if (x0 + 3 < p.dst_w) { u32x4 t = {pw[0][0], pw[1][0], pw[2][0], pw[3][0]}; __builtin_amdgcn_raw_buffer_store_b128(t, dst_rs, doff, 0, 0); }
+                        else {
+#pragma unroll
+                            for (int q = 0; q < P; ++q) if (x0 + q < p.dst_w) __builtin_amdgcn_raw_buffer_store_b32(pw[q][0], dst_rs, doff + 4 * q, 0, 0);
+                        }
+                    } else if constexpr (P == 2 && C::BPP == 8) {
+                        if (x0 + 1 < p.dst_w) { u32x4 t = {pw[0][0], pw[0][1], pw[1][0], pw[1][1]}; __builtin_amdgcn_raw_buffer_store_b128(t, dst_rs, doff, 0, 0); }
+                        else if (x0 < p.dst_w) store_px_words<CH, S16>(dst_rs, doff, pw[0]);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < P; ++q) if (x0 + q < p.dst_w) store_px_words<CH, S16>(dst_rs, doff + q * C::BPP, pw[q]);
+                    }
                     ++y;
-                    cur_need = (y < y1) ? p.y_info[y].y : 0x7fffffff;
+                    if (y < y1) {
+                        cur_need = yinfo[4 * y + 1];
+                        cur_cnt = yinfo[4 * y + 2];
+                        load_wv(y);
+                    } else {
+                        cur_need = 0x7fffffff;
+                    }
                 }
                 ++r;
             }
@@ -441,43 +566,72 @@ __global__ __launch_bounds__(256) void resize_fused_kernel(FusedParams p) {
     }
 }
 
-template <int CH, bool S16, int TX, int TYB>
-hipError_t launch_fused_t(const FusedParams &p, hipStream_t s, const char **name) {
-    constexpr int NR = RawPx<CH, S16>::kRegs;
-    constexpr int D = (TX * NR <= 8) ? 4 : (TX * NR <= 16 ? 2 : 1);
-    auto kern = resize_fused_kernel<CH, S16, TX, TYB, D>;
-    const size_t lds = (size_t)4 * p.ring_slots * kWave * sizeof(typename RingSlot<CH>::type);
+// name of the instantiation the last launch used (diagnostics / bench JSON)
+thread_local char g_kernel_name[96];
+
+template <int CH, bool S16, int P, int S, int TX, int TYB, bool FMA>
+hipError_t launch_span_t(const FusedParams &p, hipStream_t s, const char **name) {
+    auto kern = resize_span_kernel<CH, S16, P, S, TX, TYB, FMA>;
+    const size_t lds = (size_t)4 * p.ring_slots * kWave * P * sizeof(typename RingSlot<CH>::type);
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
-    dim3 grid((p.dst_w + 255) / 256, p.n_chunks, p.n_images);
+    dim3 grid((p.x_groups + 255) / 256, p.n_chunks, p.n_images);
     kern<<<grid, 256, lds, s>>>(p);
-    if (name) *name = "resize_fused_kernel";
+    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_span<ch%d,%s,P%d,S%d,TX%d,TY%d,%s>", CH, S16 ? "u16" : "u8", P, S, TX,
+             TYB, FMA ? "fma" : "exact");
+    if (name) *name = g_kernel_name;
     return hipGetLastError();
 }
 
-constexpr int kMaxFusedTX = 8;
-
-template <int CH, bool S16, int TX>
-hipError_t launch_fused_ty(const FusedParams &p, hipStream_t s, const char **name) {
-    if (p.y_pad == 8) return launch_fused_t<CH, S16, TX, 8>(p, s, name);
-    if (p.y_pad == 16) return launch_fused_t<CH, S16, TX, 16>(p, s, name);
-    return launch_fused_t<CH, S16, TX, 32>(p, s, name);
+template <int CH, bool S16, int P, int S, int TX, bool FMA>
+hipError_t launch_span_ty(const FusedParams &p, hipStream_t s, const char **name) {
+    if (p.y_pad == 8) return launch_span_t<CH, S16, P, S, TX, 8, FMA>(p, s, name);
+    if (p.y_pad == 16) return launch_span_t<CH, S16, P, S, TX, 16, FMA>(p, s, name);
+    return launch_span_t<CH, S16, P, S, TX, 32, FMA>(p, s, name);
 }
 
+template <int CH, bool S16, int P, int S, int TX>
+hipError_t launch_span_fma(const FusedParams &p, hipStream_t s, const char **name) {
+    if (p.fma) return launch_span_ty<CH, S16, P, S, TX, true>(p, s, name);
+    return launch_span_ty<CH, S16, P, S, TX, false>(p, s, name);
+}
+
+// P == 1: any tap table.  TX buckets; the host pads the weight table with zeros up to the bucket.
 template <int CH, bool S16>
-hipError_t launch_fused_tx(const FusedParams &p, hipStream_t s, const char **name) {
+hipError_t launch_span_p1(const FusedParams &p, hipStream_t s, const char **name) {
     switch (p.x_taps) {
-    case 1: return launch_fused_ty<CH, S16, 1>(p, s, name);
-    case 2: return launch_fused_ty<CH, S16, 2>(p, s, name);
-    case 3: return launch_fused_ty<CH, S16, 3>(p, s, name);
-    case 4: return launch_fused_ty<CH, S16, 4>(p, s, name);
-    case 5: return launch_fused_ty<CH, S16, 5>(p, s, name);
-    case 6: return launch_fused_ty<CH, S16, 6>(p, s, name);
-    case 7: return launch_fused_ty<CH, S16, 7>(p, s, name);
-    case 8: return launch_fused_ty<CH, S16, 8>(p, s, name);
+    case 1: return launch_span_fma<CH, S16, 1, 1, 1>(p, s, name);
+    case 2: return launch_span_fma<CH, S16, 1, 1, 2>(p, s, name);
+    case 3: return launch_span_fma<CH, S16, 1, 1, 3>(p, s, name);
+    case 4: return launch_span_fma<CH, S16, 1, 1, 4>(p, s, name);
+    case 5: return launch_span_fma<CH, S16, 1, 1, 5>(p, s, name);
+    case 6: return launch_span_fma<CH, S16, 1, 1, 6>(p, s, name);
+    case 7: return launch_span_fma<CH, S16, 1, 1, 7>(p, s, name);
+    case 8: return launch_span_fma<CH, S16, 1, 1, 8>(p, s, name);
+    case 10: return launch_span_fma<CH, S16, 1, 1, 10>(p, s, name);
+    case 12: return launch_span_fma<CH, S16, 1, 1, 12>(p, s, name);
+    case 16: return launch_span_fma<CH, S16, 1, 1, 16>(p, s, name);
+    case 20: return launch_span_fma<CH, S16, 1, 1, 20>(p, s, name);
+    case 24: return launch_span_fma<CH, S16, 1, 1, 24>(p, s, name);
+    case 32: return launch_span_fma<CH, S16, 1, 1, 32>(p, s, name);
+    }
+    return hipErrorInvalidValue;
+}
+
+// P > 1: uniform-stride tables only (host-verified); a curated list of (format, P, S, TX).
+hipError_t launch_span_multi(int pixel, const FusedParams &p, hipStream_t s, const char **name) {
+    const int key = p.x_per_lane * 10000 + p.x_step * 100 + p.x_taps;
+    if (pixel == 1) {  // rgba
+        switch (key) {
+        case 20205: return launch_span_fma<4, false, 2, 2, 5>(p, s, name);
+        case 20207: return launch_span_fma<4, false, 2, 2, 7>(p, s, name);
+        case 40205: return launch_span_fma<4, false, 4, 2, 5>(p, s, name);
+        case 20103: return launch_span_fma<4, false, 2, 1, 3>(p, s, name);
+        case 20104: return launch_span_fma<4, false, 2, 1, 4>(p, s, name);
+        }
     }
     return hipErrorInvalidValue;
 }
@@ -549,25 +703,39 @@ hipError_t launch_resize_twopass(int pixel, const TwoPassParams &p, hipStream_t 
 
 int fused_y_pad(int y_taps) { return y_taps <= 8 ? 8 : (y_taps <= 16 ? 16 : 32); }
 
-bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots) {
+int fused_x_bucket(int x_taps) {
+    static const int buckets[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32};
+    for (int b : buckets)
+        if (x_taps <= b) return b;
+    return 0;
+}
+
+bool fused_multi_supported(int pixel, int per_lane, int step, int x_taps) {
+    if (pixel != 1) return false;
+    const int key = per_lane * 10000 + step * 100 + x_taps;
+    return key == 20205 || key == 20207 || key == 40205 || key == 20103 || key == 20104;
+}
+
+bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots, int per_lane) {
     if (pixel < 0 || pixel > 7) return false;
-    if (x_taps < 1 || x_taps > kMaxFusedTX) return false;
+    if (x_taps < 1 || fused_x_bucket(x_taps) == 0) return false;
     if (y_taps < 1 || y_taps > 32) return false;
     const int ch = pixel_channels(pixel);
     const size_t slot = (ch == 1 ? 4 : ch == 2 ? 8 : 16);
-    return (size_t)4 * ring_slots * kWave * slot <= 160 * 1024;
+    return (size_t)4 * ring_slots * kWave * per_lane * slot <= 160 * 1024;
 }
 
 hipError_t launch_resize_fused(int pixel, const FusedParams &p, hipStream_t s, const char **name) {
+    if (p.x_per_lane > 1) return launch_span_multi(pixel, p, s, name);
     switch (pixel) {
-    case 0: return launch_fused_tx<3, false>(p, s, name);
-    case 1: return launch_fused_tx<4, false>(p, s, name);
-    case 2: return launch_fused_tx<1, false>(p, s, name);
-    case 3: return launch_fused_tx<2, false>(p, s, name);
-    case 4: return launch_fused_tx<1, true>(p, s, name);
-    case 5: return launch_fused_tx<2, true>(p, s, name);
-    case 6: return launch_fused_tx<3, true>(p, s, name);
-    case 7: return launch_fused_tx<4, true>(p, s, name);
+    case 0: return launch_span_p1<3, false>(p, s, name);
+    case 1: return launch_span_p1<4, false>(p, s, name);
+    case 2: return launch_span_p1<1, false>(p, s, name);
+    case 3: return launch_span_p1<2, false>(p, s, name);
+    case 4: return launch_span_p1<1, true>(p, s, name);
+    case 5: return launch_span_p1<2, true>(p, s, name);
+    case 6: return launch_span_p1<3, true>(p, s, name);
+    case 7: return launch_span_p1<4, true>(p, s, name);
     }
     return hipErrorInvalidValue;
 }

@@ -20,10 +20,17 @@ def set_path(v):
     N.check(N.lib().picha_hip_set_option(b"path", v))
 
 
+def set_opt(key, v):
+    N.check(N.lib().picha_hip_set_option(key.encode(), v))
+
+
 @pytest.fixture(autouse=True)
 def _reset_path():
     yield
     set_path(0)
+    set_opt("numerics", 0)
+    set_opt("per_lane", 0)
+    set_opt("row_chunks", 0)
 
 
 def test_device_is_gfx950():
@@ -192,3 +199,46 @@ def test_resize_async_equals_sync():
     assert box["err"] is None
     sync = picha_amd.resizeSync(img, {"width": 32, "height": 24})
     assert sync.equalPixels(box["out"])
+
+
+# ---- multi-output lanes (uniform integer scale), row chunking, and the fma numerics flavour ------------
+@pytest.mark.parametrize("per_lane", [1, 2, 4])
+def test_resize_rgba_2x_multi_output_lanes(per_lane):
+    """cfg2's structure at small size: rgba, exact 2x down, default cubic (5 taps) — every lane layout
+    of the fused kernel must be bit-identical to the oracle, including edges and a ragged last group."""
+    rng = np.random.default_rng(40 + per_lane)
+    for (sw, sh) in [(640, 480), (262, 98), (18, 10), (1030, 36)]:
+        img = rand_image(rng, sw, sh, "rgba")
+        for chunks in (0, 1, 3):
+            set_path(2)
+            set_opt("per_lane", per_lane)
+            set_opt("row_chunks", chunks)
+            got = picha_amd.resizeSync(img, {"width": sw // 2, "height": sh // 2})
+            name = N.lib().picha_hip_last_kernel().decode()
+            if per_lane > 1:
+                assert "P%d" % per_lane in name, name
+            exp = oracle_resize(img, sw // 2, sh // 2, "cubic", 0.70)
+            assert max_code_diff(got, exp) == 0, (sw, sh, per_lane, chunks, name)
+
+
+def test_resize_fma_numerics_within_one_code_value():
+    """numerics=1 (fused multiply-add flavour): tolerance stated by the north star for the
+    float-accumulated resample filters — at most ONE code value per channel."""
+    rng = np.random.default_rng(77)
+    worst = 0
+    for pixel in PIXELS:
+        for (sw, sh, dw, dh) in [(64, 48, 32, 24), (37, 29, 16, 11), (20, 14, 50, 35), (150, 120, 20, 16)]:
+            img = rand_image(rng, sw, sh, pixel)
+            for filt in FILTERS:
+                try:
+                    exp = oracle_resize(img, dw, dh, filt, 1.0)
+                except RuntimeError:
+                    continue
+                set_opt("numerics", 1)
+                got = picha_amd.resizeSync(img, {"width": dw, "height": dh, "filter": filt})
+                name = N.lib().picha_hip_last_kernel().decode()
+                d = max_code_diff(got, exp)
+                worst = max(worst, d)
+                assert d <= 1, (pixel, sw, sh, dw, dh, filt, d, name)
+    # the flavour must actually have been exercised
+    assert "fma" in name
