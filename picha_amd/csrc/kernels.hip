@@ -427,7 +427,6 @@ __global__ __launch_bounds__(256) void resize_span_kernel(FusedParams p) {
     // descriptors cover exactly one image: anything outside reads 0 / is not written
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(sbase), 0, p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t yw_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(p.y_weight), 0, p.dst_h * p.y_pad * 4, 0x00020000);
 
     const int y0 = blockIdx.y * p.rows_per_chunk;
     const int y1 = min(p.dst_h, y0 + p.rows_per_chunk);
@@ -444,8 +443,12 @@ __global__ __launch_bounds__(256) void resize_span_kernel(FusedParams p) {
 
     Slot *ring = reinterpret_cast<Slot *>(lds_raw) + (size_t)wave * p.ring_slots * (kWave * P) + lane;
 
-    const_i32_ptr yinfo = (const_i32_ptr)(p.y_info);  // int4 {left, need, count, 0} per output row
+    // All per-output-row data is wave-uniform and comes through the scalar cache (SMEM): the row's
+    // {left, need, count}, its ring slots and its weights.  Nothing but the source rows uses vector
+    // memory loads, so the compiler can count the prefetched rows exactly (s_waitcnt vmcnt(N)).
+    const_i32_ptr yinfo = (const_i32_ptr)(p.y_info);
     const_i32_ptr yslot = (const_i32_ptr)(p.y_slot);
+    const_i32_ptr ywgt = (const_i32_ptr)(p.y_weight);
     const int r0 = yinfo[4 * y0];            // first source row this chunk touches
     const int r1 = yinfo[4 * (y1 - 1) + 1];  // last
     int slot = r0 % p.ring_slots;
@@ -453,116 +456,128 @@ __global__ __launch_bounds__(256) void resize_span_kernel(FusedParams p) {
     int cur_need = yinfo[4 * y0 + 1];
     int cur_cnt = yinfo[4 * y0 + 2];
 
-    // vertical weights of the pending output row, broadcast into VGPRs (an SGPR operand would halve
-    // the VALU rate of every multiply that uses it)
-    float wv[TYB];
-    auto load_wv = [&](int yy) {
-#pragma unroll
-        for (int j = 0; j < TYB; ++j) wv[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(yw_rs, (uint32_t)(yy * p.y_pad + j) * 4u, 0, 0));
-    };
-    load_wv(y0);
-
-    uint32_t raw[D][C::NW];
+    // Source rows are double-buffered in two register sets of D rows each: while one set is being
+    // resampled the loads of the next D rows are already in flight into the other, so every
+    // s_waitcnt the compiler places leaves a full group of loads outstanding.
+    uint32_t rawA[D][C::NW], rawB[D][C::NW];
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         const int rr = min(r0 + d, r1);
-        load_span<C>(src_rs, rr * p.src_stride + lane_off, raw[d], edge_wave && rr == 0);
+        // only row 0 can produce a negative offset, and only the prologue loads row 0 into registers
+        // that are consumed (later groups start at rows >= D)
+        load_span<C>(src_rs, rr * p.src_stride + lane_off, rawA[d], d == 0 && edge_wave && rr == 0);
     }
 
-    for (int r = r0; r <= r1;) {
+    // One group = D consecutive source rows, no per-row conditionals; rows past r1 in the last group
+    // are ghosts (they re-read row r1 and land in ring slots nothing reads any more).
+    auto process_group = [&](uint32_t (&cur)[D][C::NW], uint32_t (&nxt)[D][C::NW], int r) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) load_span<C>(src_rs, min(r + D + d, r1) * p.src_stride + lane_off, nxt[d], false);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            if (r <= r1) {
-                // ---- horizontal pass of source row r (src/resize.cc:110-117) ----
-                float acc[P][SF];
+            const int row = r + d;
+            // ---- horizontal pass of source row `row` (src/resize.cc:110-117) ----
+            float acc[P][SF];
 #pragma unroll
-                for (int q = 0; q < C::SPAN; ++q) {
-                    float u[CH];
-                    unpack_span_px<C, CH, S16, !FMA>(raw[d], q, u);
+            for (int q = 0; q < C::SPAN; ++q) {
+                float u[CH];
+                unpack_span_px<C, CH, S16, !FMA>(cur[d], q, u);
 #pragma unroll
-                    for (int o = 0; o < P; ++o) {
-                        const int j = q - S * o;  // tap index of span pixel q for output o
-                        if (j >= 0 && j < TX) {
+                for (int o = 0; o < P; ++o) {
+                    const int j = q - S * o;  // tap index of span pixel q for output o
+                    if (j >= 0 && j < TX) {
 #pragma unroll
-                            for (int c = 0; c < CH; ++c) {
-                                if (j == 0) acc[o][c] = wx[o][0] * u[c];
-                                else if constexpr (FMA) acc[o][c] = __builtin_fmaf(wx[o][j], u[c], acc[o][c]);
-                                else acc[o][c] = acc[o][c] + wx[o][j] * u[c];
-                            }
+                        for (int c = 0; c < CH; ++c) {
+                            if (j == 0) acc[o][c] = wx[o][0] * u[c];
+                            else if constexpr (FMA) acc[o][c] = __builtin_fmaf(wx[o][j], u[c], acc[o][c]);
+                            else acc[o][c] = acc[o][c] + wx[o][j] * u[c];
                         }
                     }
                 }
-                // refill the prefetch slot with row r + D
-                {
-                    const int rr = min(r + D, r1);
-                    load_span<C>(src_rs, rr * p.src_stride + lane_off, raw[d], edge_wave && rr == 0);
-                }
+            }
 #pragma unroll
-                for (int o = 0; o < P; ++o) {
-                    Slot sv;
-                    if constexpr (SF == 1) sv = acc[o][0];
-                    else if constexpr (SF == 2) { sv.x = acc[o][0]; sv.y = acc[o][1]; }
-                    else { sv.x = acc[o][0]; sv.y = acc[o][1]; sv.z = acc[o][2]; sv.w = (CH == 4) ? acc[o][3] : 0.0f; }
-                    ring[(slot * P + o) * kWave] = sv;
-                }
-                slot = (slot + 1 == p.ring_slots) ? 0 : slot + 1;
+            for (int o = 0; o < P; ++o) {
+                Slot sv;
+                if constexpr (SF == 1) sv = acc[o][0];
+                else if constexpr (SF == 2) { sv.x = acc[o][0]; sv.y = acc[o][1]; }
+                else { sv.x = acc[o][0]; sv.y = acc[o][1]; sv.z = acc[o][2]; sv.w = (CH == 4) ? acc[o][3] : 0.0f; }
+                ring[(slot * P + o) * kWave] = sv;
+            }
+            slot = (slot + 1 == p.ring_slots) ? 0 : slot + 1;
 
-                // ---- vertical pass for every output row completed by row r (src/resize.cc:122-132) ----
-                while (cur_need <= r) {
-                    const_i32_ptr sy = yslot + (size_t)y * p.y_pad;
-                    float o[P][SF];
+            // ---- vertical pass for every output row completed by this row (src/resize.cc:122-132) ----
+            while (cur_need <= row) {
+                const_i32_ptr sy = yslot + (size_t)y * p.y_pad;
+                const_i32_ptr wy = ywgt + (size_t)y * p.y_pad;
+                float o[P][SF];
 #pragma unroll
-                    for (int j = 0; j < TYB; ++j) {
+                for (int j0 = 0; j0 < TYB; j0 += 8) {
+                    if (j0 >= cur_cnt) break;
+                    int sl[8], wb[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { sl[j] = sy[j0 + j]; wb[j] = wy[j0 + j]; }  // two s_load_dwordx8
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int j = j0 + jj;
                         if (j >= cur_cnt) break;
-                        const int sj = sy[j];
+                        // weight into a VGPR: an SGPR operand would halve the rate of every multiply below
+                        float w;
+                        asm volatile("v_mov_b32 %0, %1" : "=v"(w) : "s"(wb[jj]));
 #pragma unroll
                         for (int q = 0; q < P; ++q) {
-                            const Slot v = ring[(sj * P + q) * kWave];
+                            const Slot v = ring[(sl[jj] * P + q) * kWave];
                             float vf[SF];
                             if constexpr (SF == 1) vf[0] = v;
                             else if constexpr (SF == 2) { vf[0] = v.x; vf[1] = v.y; }
                             else { vf[0] = v.x; vf[1] = v.y; vf[2] = v.z; vf[3] = v.w; }
 #pragma unroll
                             for (int c = 0; c < CH; ++c) {
-                                if (j == 0) o[q][c] = wv[0] * vf[c];
-                                else if constexpr (FMA) o[q][c] = __builtin_fmaf(wv[j], vf[c], o[q][c]);
-                                else o[q][c] = o[q][c] + wv[j] * vf[c];
+                                if (j == 0) o[q][c] = w * vf[c];
+                                else if constexpr (FMA) o[q][c] = __builtin_fmaf(w, vf[c], o[q][c]);
+                                else o[q][c] = o[q][c] + w * vf[c];
                             }
                         }
                     }
-                    // pack + store this lane's P pixels of output row y
-                    const uint32_t doff = uint32_t(y * p.dst_stride + x0 * C::BPP);
-                    uint32_t pw[P][2];
-#pragma unroll
-                    for (int q = 0; q < P; ++q) pack_px_words<CH, S16, FMA>(o[q], pw[q]);
-                    if constexpr (P == 2 && C::BPP == 4) {
-                        if (x0 + 1 < p.dst_w) { u32x2 t = {pw[0][0], pw[1][0]}; __builtin_amdgcn_raw_buffer_store_b64(t, dst_rs, doff, 0, 0); }
-                        else if (x0 < p.dst_w) __builtin_amdgcn_raw_buffer_store_b32(pw[0][0], dst_rs, doff, 0, 0);
-                    } else if constexpr (P == 4 && C::BPP == 4) {
-                        if (x0 + 3 < p.dst_w) { u32x4 t = {pw[0][0], pw[1][0], pw[2][0], pw[3][0]}; __builtin_amdgcn_raw_buffer_store_b128(t, dst_rs, doff, 0, 0); }
-                        else {
-#pragma unroll
-                            for (int q = 0; q < P; ++q) if (x0 + q < p.dst_w) __builtin_amdgcn_raw_buffer_store_b32(pw[q][0], dst_rs, doff + 4 * q, 0, 0);
-                        }
-                    } else if constexpr (P == 2 && C::BPP == 8) {
-                        if (x0 + 1 < p.dst_w) { u32x4 t = {pw[0][0], pw[0][1], pw[1][0], pw[1][1]}; __builtin_amdgcn_raw_buffer_store_b128(t, dst_rs, doff, 0, 0); }
-                        else if (x0 < p.dst_w) store_px_words<CH, S16>(dst_rs, doff, pw[0]);
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < P; ++q) if (x0 + q < p.dst_w) store_px_words<CH, S16>(dst_rs, doff + q * C::BPP, pw[q]);
-                    }
-                    ++y;
-                    if (y < y1) {
-                        cur_need = yinfo[4 * y + 1];
-                        cur_cnt = yinfo[4 * y + 2];
-                        load_wv(y);
-                    } else {
-                        cur_need = 0x7fffffff;
-                    }
                 }
-                ++r;
+                // pack + store this lane's P pixels of output row y
+                const uint32_t doff = uint32_t(y * p.dst_stride + x0 * C::BPP);
+                uint32_t pw[P][2];
+#pragma unroll
+                for (int q = 0; q < P; ++q) pack_px_words<CH, S16, FMA>(o[q], pw[q]);
+                if constexpr (P == 2 && C::BPP == 4) {
+                    if (x0 + 1 < p.dst_w) { u32x2 t = {pw[0][0], pw[1][0]}; __builtin_amdgcn_raw_buffer_store_b64(t, dst_rs, doff, 0, 0); }
+                    else if (x0 < p.dst_w) __builtin_amdgcn_raw_buffer_store_b32(pw[0][0], dst_rs, doff, 0, 0);
+                } else if constexpr (P == 4 && C::BPP == 4) {
+                    if (x0 + 3 < p.dst_w) { u32x4 t = {pw[0][0], pw[1][0], pw[2][0], pw[3][0]}; __builtin_amdgcn_raw_buffer_store_b128(t, dst_rs, doff, 0, 0); }
+                    else {
+#pragma unroll
+                        for (int q = 0; q < P; ++q) if (x0 + q < p.dst_w) __builtin_amdgcn_raw_buffer_store_b32(pw[q][0], dst_rs, doff + 4 * q, 0, 0);
+                    }
+                } else if constexpr (P == 2 && C::BPP == 8) {
+                    if (x0 + 1 < p.dst_w) { u32x4 t = {pw[0][0], pw[0][1], pw[1][0], pw[1][1]}; __builtin_amdgcn_raw_buffer_store_b128(t, dst_rs, doff, 0, 0); }
+                    else if (x0 < p.dst_w) store_px_words<CH, S16>(dst_rs, doff, pw[0]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < P; ++q) if (x0 + q < p.dst_w) store_px_words<CH, S16>(dst_rs, doff + q * C::BPP, pw[q]);
+                }
+                ++y;
+                if (y < y1) {
+                    cur_need = yinfo[4 * y + 1];
+                    cur_cnt = yinfo[4 * y + 2];
+                } else {
+                    cur_need = 0x7fffffff;
+                }
             }
         }
+    };
+
+    for (int r = r0;;) {
+        process_group(rawA, rawB, r);
+        r += D;
+        if (r > r1) break;
+        process_group(rawB, rawA, r);
+        r += D;
+        if (r > r1) break;
     }
 }
 
@@ -603,13 +618,16 @@ hipError_t launch_span_fma(const FusedParams &p, hipStream_t s, const char **nam
 template <int CH, bool S16>
 hipError_t launch_span_p1(const FusedParams &p, hipStream_t s, const char **name) {
     switch (p.x_taps) {
+#ifndef PICHA_QUICK  // PICHA_QUICK: developer build that only instantiates the flagship tap counts
     case 1: return launch_span_fma<CH, S16, 1, 1, 1>(p, s, name);
     case 2: return launch_span_fma<CH, S16, 1, 1, 2>(p, s, name);
     case 3: return launch_span_fma<CH, S16, 1, 1, 3>(p, s, name);
     case 4: return launch_span_fma<CH, S16, 1, 1, 4>(p, s, name);
-    case 5: return launch_span_fma<CH, S16, 1, 1, 5>(p, s, name);
     case 6: return launch_span_fma<CH, S16, 1, 1, 6>(p, s, name);
+#endif
+    case 5: return launch_span_fma<CH, S16, 1, 1, 5>(p, s, name);
     case 7: return launch_span_fma<CH, S16, 1, 1, 7>(p, s, name);
+#ifndef PICHA_QUICK
     case 8: return launch_span_fma<CH, S16, 1, 1, 8>(p, s, name);
     case 10: return launch_span_fma<CH, S16, 1, 1, 10>(p, s, name);
     case 12: return launch_span_fma<CH, S16, 1, 1, 12>(p, s, name);
@@ -617,6 +635,7 @@ hipError_t launch_span_p1(const FusedParams &p, hipStream_t s, const char **name
     case 20: return launch_span_fma<CH, S16, 1, 1, 20>(p, s, name);
     case 24: return launch_span_fma<CH, S16, 1, 1, 24>(p, s, name);
     case 32: return launch_span_fma<CH, S16, 1, 1, 32>(p, s, name);
+#endif
     }
     return hipErrorInvalidValue;
 }
@@ -728,14 +747,16 @@ bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots, int per_
 hipError_t launch_resize_fused(int pixel, const FusedParams &p, hipStream_t s, const char **name) {
     if (p.x_per_lane > 1) return launch_span_multi(pixel, p, s, name);
     switch (pixel) {
-    case 0: return launch_span_p1<3, false>(p, s, name);
     case 1: return launch_span_p1<4, false>(p, s, name);
+#ifndef PICHA_QUICK
+    case 0: return launch_span_p1<3, false>(p, s, name);
     case 2: return launch_span_p1<1, false>(p, s, name);
     case 3: return launch_span_p1<2, false>(p, s, name);
     case 4: return launch_span_p1<1, true>(p, s, name);
     case 5: return launch_span_p1<2, true>(p, s, name);
     case 6: return launch_span_p1<3, true>(p, s, name);
     case 7: return launch_span_p1<4, true>(p, s, name);
+#endif
     }
     return hipErrorInvalidValue;
 }
