@@ -55,7 +55,7 @@ bool valid_pixel(int p) { return p >= 0 && p < PICHA_NUM_PIXELS; }
 
 // ---- options -----------------------------------------------------------------------------------
 std::mutex g_opt_mu;
-long g_opt_path = 0;        // 0 auto, 1 two-pass, 2 fused (error if unsupported)
+long g_opt_path = 0;        // 0 auto, 1 two-pass, 2 fused (error if unsupported), 3 fused but never the streaming kernel
 long g_opt_row_chunks = 0;  // 0 auto
 long g_opt_numerics = 0;    // 0 reference arithmetic (bit-exact), 1 fused-multiply-add flavour (<= 1 code value)
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
@@ -76,6 +76,14 @@ struct DeviceAxis {
         int groups = 0, stride = 0;
     };
     std::map<std::tuple<int, int, int, int, int>, XTable> xtables;
+    // streaming kernel, y role: uniform-stride view of the table, built on demand per (step, taps)
+    struct YStream {
+        bool ok = false;
+        void *blob = nullptr;
+        float *step_weight = nullptr;  // [dst + (taps-1)/step][yw]
+        int base = 0;                  // output y reads source rows step*y + base + j
+    };
+    std::map<std::pair<int, int>, YStream> ystreams;
     // fused, y role
     int4 *y_info = nullptr;
     float *y_weight = nullptr;  // [dst][y_pad]
@@ -271,6 +279,51 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
     return PICHA_OK;
 }
 
+// Vertical table for the streaming kernel.  Valid when every output row's taps fit the uniform window
+// rows [step*y + base, step*y + base + taps) and the reference's ring never aliases (SURVEY quirk 1:
+// then the rows read are exactly left + j).  Layout: one record per step m (= SY source rows);
+// entry i*step + ph is the weight output m - i applies to source row step*m + base + ph, i.e. its
+// tap step*i + ph (0 where the output does not exist or the tap is padding).
+int get_ystream(DeviceCtx *ctx, DeviceAxis *ay, int step, int taps, const DeviceAxis::YStream **out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto key = std::make_pair(step, taps);
+    auto it = ay->ystreams.find(key);
+    if (it != ay->ystreams.end()) { *out = &it->second; return PICHA_OK; }
+    DeviceAxis::YStream ys;
+    const AxisTaps &t = ay->host;
+    const int dst = t.dst_size, T = t.taps;
+    int base = INT32_MAX;
+    for (int y = 0; y < dst; ++y) base = std::min(base, t.left[y] - step * y);
+    bool ok = true;
+    for (int y = 0; y < dst && ok; ++y) {
+        if (t.left[y] - (step * y + base) + t.count[y] > taps) ok = false;
+        for (int j = 0; j < t.count[y] && ok; ++j)
+            if (t.eff[(size_t)y * T + j] != t.left[y] + j) ok = false;  // ring aliasing: not representable
+    }
+    ys.ok = ok;
+    ys.base = base;
+    if (ok) {
+        const int npend = (taps - 1) / step + 1, iclose = (taps - 1) / step;
+        const int yw = (npend * step + 3) / 4 * 4;
+        const int nsteps = dst + iclose;
+        std::vector<float> tab((size_t)nsteps * yw, 0.0f);
+        for (int y = 0; y < dst; ++y) {
+            const int first = t.left[y] - (step * y + base);
+            for (int j = 0; j < t.count[y]; ++j) {
+                const int tap = first + j;            // position in the uniform window
+                const int i = tap / step, ph = tap % step;
+                tab[(size_t)(y + i) * yw + i * step + ph] = t.weight[(size_t)y * T + j];
+            }
+        }
+        HIP_TRY(hipMalloc(&ys.blob, tab.size() * sizeof(float)));
+        HIP_TRY(hipMemcpy(ys.blob, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+        ys.step_weight = static_cast<float *>(ys.blob);
+    }
+    auto ins = ay->ystreams.emplace(key, ys);
+    *out = &ins.first->second;
+    return PICHA_OK;
+}
+
 // ---- validation ----------------------------------------------------------------------------------
 int check_src(const picha_image *im) {
     // jsImageToNativeImage (src/picha.cc:61-85): valid pixel, data present, height != 0
@@ -378,6 +431,62 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             if (cx->ok) { xt = cx; per_lane = pl; step = st; ktaps = ax->host.taps; break; }
         }
     }
+    // ---- streaming kernel (uniform tables in x and y, no LDS): preferred when available
+    if (fused_ok && opt_path != 1 && opt_path != 3) {
+        const int sx = std::max(1, (int)std::lround((double)s0.width / d0.width));
+        const int sy = std::max(1, (int)std::lround((double)s0.height / d0.height));
+        static const int cand_s[] = {2, 1, 4};
+        for (int pl : cand_s) {
+            if (opt_per_lane > 0 && pl != opt_per_lane) continue;
+            if (opt_per_lane == 0 && pl != 2) continue;
+            if (!stream_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps)) continue;
+            const DeviceAxis::XTable *cx = nullptr;
+            const DeviceAxis::YStream *cy = nullptr;
+            rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, fma, is16, &cx);
+            if (rc) return rc;
+            rc = get_ystream(ctx, ay, sy, ay->host.taps, &cy);
+            if (rc) return rc;
+            if (!cx->ok || !cy->ok) continue;
+            StreamParams p{};
+            long long sp = 0, dp = 0;
+            TablePair tab;
+            std::unique_lock<std::mutex> temp_lock(ctx->temp_mu, std::defer_lock);
+            if (uniform_pitch(src, n, &sp) && uniform_pitch(dst, n, &dp)) {
+                p.src = static_cast<const uint8_t *>(s0.data);
+                p.dst = static_cast<uint8_t *>(d0.data);
+                p.src_pitch = sp; p.dst_pitch = dp;
+            } else {
+                temp_lock.lock();
+                rc = make_tables(ctx, src, dst, n, s, &tab);
+                if (rc) return rc;
+                p.src_tab = tab.src; p.dst_tab = tab.dst;
+            }
+            p.src_stride = s0.stride; p.dst_stride = d0.stride;
+            p.src_w = s0.width; p.src_h = s0.height; p.dst_w = d0.width; p.dst_h = d0.height;
+            p.src_bytes = (unsigned)src_span; p.dst_bytes = (unsigned)dst_span;
+            p.x_left = cx->left; p.x_weight = cx->weight; p.x_taps = ax->host.taps;
+            p.x_per_lane = pl; p.x_step = sx; p.x_groups = cx->groups; p.xw_stride = cx->stride;
+            p.fma = fma;
+            p.y_step_weight = cy->step_weight; p.y_step = sy; p.y_taps = ay->host.taps; p.y_base = cy->base;
+            const long long col_waves = (cx->groups + 63) / 64;
+            long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
+            chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
+            p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
+            p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
+            int done = 0;
+            while (done < n) {
+                const int m = std::min(n - done, 65535);
+                StreamParams q = p;
+                q.n_images = m;
+                if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
+                else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
+                HIP_TRY(launch_resize_stream_kernel(pixel, q, s, &g_last_kernel));
+                done += m;
+            }
+            if (tab.used) return temp_release(ctx->tables, s);
+            return PICHA_OK;
+        }
+    }
     if (fused_ok && !xt) {
         fused_ok = ktaps > 0 && fused_supported(pixel, ktaps, ay->host.taps, ring, 1);
         if (fused_ok) {
@@ -386,7 +495,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             fused_ok = xt->ok;
         }
     }
-    if (opt_path == 2 && !fused_ok) return fail(PICHA_ERR_ARGUMENT, "fused kernel forced but unsupported for this geometry");
+    if ((opt_path == 2 || opt_path == 3) && !fused_ok) return fail(PICHA_ERR_ARGUMENT, "fused kernel forced but unsupported for this geometry");
     const bool use_fused = fused_ok && opt_path != 1;
 
     if (use_fused) {

@@ -78,6 +78,29 @@ int fused_x_bucket(int x_taps);
 int fused_y_pad(int y_taps);
 hipError_t launch_resize_fused(int pixel, const FusedParams &p, hipStream_t s, const char **kernel_name);
 
+// ---- resize: streaming kernel for uniform tap tables (no LDS) --------------------------------------
+struct StreamParams {
+    const uint8_t *src;
+    uint8_t *dst;
+    long long src_pitch, dst_pitch;
+    const void *const *src_tab;
+    void *const *dst_tab;
+    int src_stride, dst_stride;
+    int src_w, src_h, dst_w, dst_h;
+    unsigned src_bytes, dst_bytes;
+    int n_images;
+    const int32_t *x_left;
+    const float *x_weight;
+    int x_taps, x_per_lane, x_step, x_groups, xw_stride;
+    int fma;
+    // output row y reads source rows y_step*y + y_base + j, j < y_taps
+    const float *y_step_weight;  // [dst_h + (y_taps-1)/y_step][YW]; YW = roundup4(ceil(y_taps/y_step)*y_step)
+    int y_step, y_taps, y_base;
+    int rows_per_chunk, n_chunks;
+};
+bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty);
+hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
+
 // ---- synthetic pixels ---------------------------------------------------------------------------
 hipError_t launch_fill_random(void *dev, size_t bytes, uint64_t seed, int sample_bytes, hipStream_t s);
 void fill_random_host(void *host, size_t bytes, uint64_t seed, int sample_bytes);

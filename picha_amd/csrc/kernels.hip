@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <type_traits>
 
 #pragma clang fp contract(off)
 
@@ -307,15 +308,16 @@ template <int CH, bool S16, int P, int S, int TX> struct SpanCfg {
     static_assert(WORDS || P == 1, "multi-output lanes need dword-sized pixels");
 };
 
-// `careful` (wave-uniform): some lane's span starts before the image (negative offset; only possible
-// in row 0 for the left-most lane group of multi-output lanes).  A wrapped 32-bit offset would put
-// the WHOLE merged multi-dword load out of range, so those dwords are clamped one by one instead
-// (they only ever meet zero weights).
-template <typename C>
-__device__ __forceinline__ void load_span(__amdgpu_buffer_rsrc_t rsrc, int32_t off, uint32_t *raw, bool careful) {
+// CAREFUL: some lane of this wave has a span that starts before the image (negative offset; only the
+// left-most lane group of multi-output lanes, and only in row 0, where there is no previous row for
+// the offset to land in).  A wrapped 32-bit offset would put the WHOLE merged multi-dword load out
+// of range, so such waves clamp every dword's offset separately (the clamped dwords only ever meet
+// zero weights).  Waves without such a lane run the merged-load instantiation.
+template <typename C, bool CAREFUL>
+__device__ __forceinline__ void load_span(__amdgpu_buffer_rsrc_t rsrc, int32_t off, uint32_t *raw) {
     const uint32_t voff = uint32_t(off);
     if constexpr (C::WORDS) {
-        if (careful) {
+        if constexpr (CAREFUL) {
 #pragma unroll
             for (int i = 0; i < C::NW; ++i) raw[i] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, uint32_t(max(off + 4 * i, 0)), 0, 0);
         } else {
@@ -455,24 +457,28 @@ __global__ __launch_bounds__(256) void resize_span_kernel(FusedParams p) {
     int y = y0;
     int cur_need = yinfo[4 * y0 + 1];
     int cur_cnt = yinfo[4 * y0 + 2];
+    // TYB == 8: the pending output row's slots and weights are fetched one output row ahead
+    // (SMEM latency would otherwise sit on the critical path of every vertical pass)
+    int psl[8], pwb[8];
+    if constexpr (TYB == 8) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { psl[j] = yslot[(size_t)y0 * 8 + j]; pwb[j] = ywgt[(size_t)y0 * 8 + j]; }
+    }
 
     // Source rows are double-buffered in two register sets of D rows each: while one set is being
     // resampled the loads of the next D rows are already in flight into the other, so every
     // s_waitcnt the compiler places leaves a full group of loads outstanding.
+    auto march = [&](auto careful_c) __attribute__((always_inline)) {
+    constexpr bool CAREFUL = decltype(careful_c)::value;
     uint32_t rawA[D][C::NW], rawB[D][C::NW];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        const int rr = min(r0 + d, r1);
-        // only row 0 can produce a negative offset, and only the prologue loads row 0 into registers
-        // that are consumed (later groups start at rows >= D)
-        load_span<C>(src_rs, rr * p.src_stride + lane_off, rawA[d], d == 0 && edge_wave && rr == 0);
-    }
+    for (int d = 0; d < D; ++d) load_span<C, CAREFUL>(src_rs, min(r0 + d, r1) * p.src_stride + lane_off, rawA[d]);
 
     // One group = D consecutive source rows, no per-row conditionals; rows past r1 in the last group
     // are ghosts (they re-read row r1 and land in ring slots nothing reads any more).
-    auto process_group = [&](uint32_t (&cur)[D][C::NW], uint32_t (&nxt)[D][C::NW], int r) {
+    auto process_group = [&](uint32_t (&cur)[D][C::NW], uint32_t (&nxt)[D][C::NW], int r) __attribute__((always_inline)) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) load_span<C>(src_rs, min(r + D + d, r1) * p.src_stride + lane_off, nxt[d], false);
+        for (int d = 0; d < D; ++d) load_span<C, CAREFUL>(src_rs, min(r + D + d, r1) * p.src_stride + lane_off, nxt[d]);
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             const int row = r + d;
@@ -514,8 +520,13 @@ __global__ __launch_bounds__(256) void resize_span_kernel(FusedParams p) {
                 for (int j0 = 0; j0 < TYB; j0 += 8) {
                     if (j0 >= cur_cnt) break;
                     int sl[8], wb[8];
+                    if constexpr (TYB == 8) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) { sl[j] = sy[j0 + j]; wb[j] = wy[j0 + j]; }  // two s_load_dwordx8
+                        for (int j = 0; j < 8; ++j) { sl[j] = psl[j]; wb[j] = pwb[j]; }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { sl[j] = sy[j0 + j]; wb[j] = wy[j0 + j]; }  // two s_load_dwordx8
+                    }
 #pragma unroll
                     for (int jj = 0; jj < 8; ++jj) {
                         const int j = j0 + jj;
@@ -564,6 +575,10 @@ __global__ __launch_bounds__(256) void resize_span_kernel(FusedParams p) {
                 if (y < y1) {
                     cur_need = yinfo[4 * y + 1];
                     cur_cnt = yinfo[4 * y + 2];
+                    if constexpr (TYB == 8) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { psl[j] = yslot[(size_t)y * 8 + j]; pwb[j] = ywgt[(size_t)y * 8 + j]; }
+                    }
                 } else {
                     cur_need = 0x7fffffff;
                 }
@@ -579,10 +594,210 @@ __global__ __launch_bounds__(256) void resize_span_kernel(FusedParams p) {
         r += D;
         if (r > r1) break;
     }
+    };  // march
+    if (edge_wave) march(std::true_type{});
+    else march(std::false_type{});
+}
+
+// ---------------------------------------------------------------------------------------------
+// Streaming resize kernel for uniform tap tables (integer scale factors): no LDS at all.
+//
+// Same horizontal scheme as the span kernel.  Vertically the tap table must be uniform too: output
+// row y reads source rows SY*y + y_base + j, j < TY (host-verified; zero-weight padding at the image
+// edges).  Then every resampled source row contributes to a fixed set of pending output rows, so
+// instead of keeping a ring of resampled rows the kernel keeps NPEND = ceil(TY / SY) output
+// accumulators in registers and folds each resampled row into them the moment it is produced.
+// Rows arrive in ascending order, so every output still sums its taps in ascending source order
+// exactly as the reference does (src/resize.cc:125-129) — bit-exact in the non-FMA flavour.
+// "Step" m = the SY source rows SY*m + y_base + ph (ph < SY); row ph of step m is tap SY*i + ph of
+// output m - i.  Output m - ICLOSE is complete after row PHCLOSE of step m.
+// Rows outside the image read as zeros through the buffer descriptor (their weights are zero).
+// ---------------------------------------------------------------------------------------------
+constexpr int ce_gcd(int a, int b) { return b == 0 ? a : ce_gcd(b, a % b); }
+
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA>
+__global__ __launch_bounds__(256) void resize_stream_kernel(StreamParams p) {
+    using C = SpanCfg<CH, S16, P, SX, TX>;
+    constexpr int NPEND = (TY - 1) / SY + 1;
+    constexpr int ICLOSE = (TY - 1) / SY, PHCLOSE = (TY - 1) % SY;
+    constexpr int YW = (NPEND * SY + 3) / 4 * 4;           // floats per step in the step-weight table
+    constexpr int UNR = NPEND * 2 / ce_gcd(NPEND, 2);      // lcm(NPEND, 2): accumulator roles x A/B buffers
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp0 = (blockIdx.x * 4 + wave) * kWave;
+    if (grp0 * P >= p.dst_w) return;
+    const int grp = min(grp0 + lane, p.x_groups - 1);
+    const int x0 = (grp0 + lane) * P;
+
+    const int img = blockIdx.z;
+    const uint8_t *sbase = p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch;
+    uint8_t *dbase = p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch;
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(sbase), 0, p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
+
+    const int y0 = blockIdx.y * p.rows_per_chunk;
+    const int y1 = min(p.dst_h, y0 + p.rows_per_chunk);
+    if (y0 >= y1) return;
+    const int m_end = y1 - 1 + ICLOSE;  // last step that completes an output of this chunk
+
+    float wx[P][TX];
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+#pragma unroll
+        for (int j = 0; j < TX; ++j) wx[q][j] = p.x_weight[(size_t)j * p.xw_stride + grp * P + q];
+    const int32_t lane_off = p.x_left[grp] * C::BPP;
+    const bool edge_wave = P > 1 && __any(lane_off < 0);
+    const_i32_ptr ystep = (const_i32_ptr)(p.y_step_weight);
+
+    auto march = [&](auto careful_c) __attribute__((always_inline)) {
+    constexpr bool CAREFUL = decltype(careful_c)::value;
+    float acc[NPEND][P][CH];
+    uint32_t rawA[SY][C::NW], rawB[SY][C::NW];
+
+    auto load_step = [&](uint32_t (&t)[SY][C::NW], int m) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ph = 0; ph < SY; ++ph) {
+            const int row = SY * m + p.y_base + ph;
+            // rows < 0 or >= src_h give offsets outside the image's descriptor: they read 0
+            const int rr = (row >= p.src_h) ? p.src_h : row;  // keep row * stride far from int overflow
+            load_span<C, CAREFUL>(src_rs, rr * p.src_stride + lane_off, t[ph]);
+        }
+    };
+
+    auto step = [&](uint32_t (&cur)[SY][C::NW], uint32_t (&nxt)[SY][C::NW], int m, auto kc) __attribute__((always_inline)) {
+        constexpr int K = decltype(kc)::value;  // (m - y0) mod NPEND, static thanks to the unrolling
+        load_step(nxt, m + 1);
+        // this step's vertical weights: entry i*SY + ph = weight of output m - i for source row ph
+        float wy[NPEND][SY];
+        {
+            int wb[YW];
+#pragma unroll
+            for (int t = 0; t < YW; ++t) wb[t] = ystep[(size_t)m * YW + t];
+#pragma unroll
+            for (int i = 0; i < NPEND; ++i)
+#pragma unroll
+                for (int ph = 0; ph < SY; ++ph)
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(wy[i][ph]) : "s"(wb[i * SY + ph]));  // VGPR operand: full VALU rate
+        }
+#pragma unroll
+        for (int ph = 0; ph < SY; ++ph) {
+            // ---- horizontal pass (src/resize.cc:110-117) ----
+            float h[P][CH];
+#pragma unroll
+            for (int q = 0; q < C::SPAN; ++q) {
+                float u[CH];
+                unpack_span_px<C, CH, S16, !FMA>(cur[ph], q, u);
+#pragma unroll
+                for (int o = 0; o < P; ++o) {
+                    const int j = q - SX * o;
+                    if (j >= 0 && j < TX) {
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            if (j == 0) h[o][c] = wx[o][0] * u[c];
+                            else if constexpr (FMA) h[o][c] = __builtin_fmaf(wx[o][j], u[c], h[o][c]);
+                            else h[o][c] = h[o][c] + wx[o][j] * u[c];
+                        }
+                    }
+                }
+            }
+            // ---- fold into the pending outputs (src/resize.cc:125-129, one tap per output) ----
+#pragma unroll
+            for (int i = 0; i < NPEND; ++i) {
+                const int j = SY * i + ph;
+                if (j < TY) {
+                    constexpr int dummy = 0; (void)dummy;
+                    const int sl = (K - i + 4 * NPEND) % NPEND;
+#pragma unroll
+                    for (int o = 0; o < P; ++o)
+#pragma unroll
+                        for (int c = 0; c < CH; ++c) {
+                            if (j == 0) acc[sl][o][c] = wy[i][ph] * h[o][c];
+                            else if constexpr (FMA) acc[sl][o][c] = __builtin_fmaf(wy[i][ph], h[o][c], acc[sl][o][c]);
+                            else acc[sl][o][c] = acc[sl][o][c] + wy[i][ph] * h[o][c];
+                        }
+                }
+            }
+            if (ph == PHCLOSE) {
+                const int y = m - ICLOSE;
+                if (y >= y0) {  // outputs of the previous chunk are produced there
+                    const int sl = (K - ICLOSE + 4 * NPEND) % NPEND;
+                    const uint32_t doff = uint32_t(y * p.dst_stride + x0 * C::BPP);
+                    uint32_t pw[P][2];
+#pragma unroll
+                    for (int q = 0; q < P; ++q) pack_px_words<CH, S16, FMA>(acc[sl][q], pw[q]);
+                    if constexpr (P == 2 && C::BPP == 4) {
+                        if (x0 + 1 < p.dst_w) { u32x2 t = {pw[0][0], pw[1][0]}; __builtin_amdgcn_raw_buffer_store_b64(t, dst_rs, doff, 0, 0); }
+                        else if (x0 < p.dst_w) __builtin_amdgcn_raw_buffer_store_b32(pw[0][0], dst_rs, doff, 0, 0);
+                    } else if constexpr (P == 4 && C::BPP == 4) {
+                        if (x0 + 3 < p.dst_w) { u32x4 t = {pw[0][0], pw[1][0], pw[2][0], pw[3][0]}; __builtin_amdgcn_raw_buffer_store_b128(t, dst_rs, doff, 0, 0); }
+                        else {
+#pragma unroll
+                            for (int q = 0; q < P; ++q) if (x0 + q < p.dst_w) __builtin_amdgcn_raw_buffer_store_b32(pw[q][0], dst_rs, doff + 4 * q, 0, 0);
+                        }
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < P; ++q) if (x0 + q < p.dst_w) store_px_words<CH, S16>(dst_rs, doff + q * C::BPP, pw[q]);
+                    }
+                }
+            }
+        }
+    };
+
+    load_step(rawA, y0);
+    for (int m = y0; m <= m_end; m += UNR) {
+        // UNR steps, fully unrolled: accumulator roles and the A/B buffers are compile-time
+        auto run = [&](auto self, auto kc) __attribute__((always_inline)) -> void {
+            constexpr int k = decltype(kc)::value;
+            if constexpr (k < UNR) {
+                if (m + k <= m_end) {
+                    if constexpr (k % 2 == 0) step(rawA, rawB, m + k, std::integral_constant<int, k % NPEND>{});
+                    else step(rawB, rawA, m + k, std::integral_constant<int, k % NPEND>{});
+                    self(self, std::integral_constant<int, k + 1>{});
+                }
+            }
+        };
+        run(run, std::integral_constant<int, 0>{});
+    }
+    };  // march
+    if (edge_wave) march(std::true_type{});
+    else march(std::false_type{});
 }
 
 // name of the instantiation the last launch used (diagnostics / bench JSON)
 thread_local char g_kernel_name[96];
+
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY>
+hipError_t launch_stream_t(const StreamParams &p, hipStream_t s, const char **name) {
+    dim3 grid((p.x_groups + 255) / 256, p.n_chunks, p.n_images);
+    if (p.fma) resize_stream_kernel<CH, S16, P, SX, TX, SY, TY, true><<<grid, 256, 0, s>>>(p);
+    else resize_stream_kernel<CH, S16, P, SX, TX, SY, TY, false><<<grid, 256, 0, s>>>(p);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_stream<ch%d,%s,P%d,SX%d,TX%d,SY%d,TY%d,%s>", CH, S16 ? "u16" : "u8", P, SX,
+             TX, SY, TY, p.fma ? "fma" : "exact");
+    if (name) *name = g_kernel_name;
+    return hipGetLastError();
+}
+
+// curated list of streaming instantiations: key = pixel, P, SX, TX, SY, TY
+#define PICHA_STREAM_LIST(X) \
+    X(1, 4, false, 1, 2, 5, 2, 5) X(1, 4, false, 2, 2, 5, 2, 5) X(1, 4, false, 4, 2, 5, 2, 5) \
+    X(1, 4, false, 1, 2, 7, 2, 7) X(1, 4, false, 2, 2, 7, 2, 7)
+
+bool stream_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty) {
+#define X(PIX, CH, S16, P, SX, TX, SY, TY) if (pixel == PIX && per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY) return true;
+    PICHA_STREAM_LIST(X)
+#undef X
+    return false;
+}
+
+hipError_t launch_resize_stream(int pixel, const StreamParams &p, hipStream_t s, const char **name) {
+#define X(PIX, CH, S16, P, SX, TX, SY, TY) \
+    if (pixel == PIX && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY) \
+        return launch_stream_t<CH, S16, P, SX, TX, SY, TY>(p, s, name);
+    PICHA_STREAM_LIST(X)
+#undef X
+    return hipErrorInvalidValue;
+}
 
 template <int CH, bool S16, int P, int S, int TX, int TYB, bool FMA>
 hipError_t launch_span_t(const FusedParams &p, hipStream_t s, const char **name) {
@@ -687,6 +902,16 @@ __global__ __launch_bounds__(256) void fill_random_kernel(uint8_t *dst, size_t b
     }
 }
 
+}  // namespace
+
+bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty) {
+    return stream_supported(pixel, per_lane, sx, tx, sy, ty);
+}
+hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **name) {
+    return launch_resize_stream(pixel, p, s, name);
+}
+
+namespace {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------

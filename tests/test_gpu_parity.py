@@ -209,16 +209,35 @@ def test_resize_rgba_2x_multi_output_lanes(per_lane):
     rng = np.random.default_rng(40 + per_lane)
     for (sw, sh) in [(640, 480), (262, 98), (18, 10), (1030, 36)]:
         img = rand_image(rng, sw, sh, "rgba")
+        exp = oracle_resize(img, sw // 2, sh // 2, "cubic", 0.70)
+        exp7 = oracle_resize(img, sw // 2, sh // 2, "cubic", 1.0)
         for chunks in (0, 1, 3):
-            set_path(2)
-            set_opt("per_lane", per_lane)
-            set_opt("row_chunks", chunks)
-            got = picha_amd.resizeSync(img, {"width": sw // 2, "height": sh // 2})
-            name = N.lib().picha_hip_last_kernel().decode()
-            if per_lane > 1:
+            for path, family in ((2, "resize_stream"), (3, "resize_span")):  # streaming (no LDS) and LDS-ring kernels
+                set_path(path)
+                set_opt("per_lane", per_lane)
+                set_opt("row_chunks", chunks)
+                got = picha_amd.resizeSync(img, {"width": sw // 2, "height": sh // 2})
+                name = N.lib().picha_hip_last_kernel().decode()
+                assert name.startswith(family), name
                 assert "P%d" % per_lane in name, name
-            exp = oracle_resize(img, sw // 2, sh // 2, "cubic", 0.70)
-            assert max_code_diff(got, exp) == 0, (sw, sh, per_lane, chunks, name)
+                assert max_code_diff(got, exp) == 0, (sw, sh, per_lane, chunks, name)
+                if per_lane <= 2:  # 7-tap variant ({filter: 'cubic'} resets filterScale to 1.0)
+                    got = picha_amd.resizeSync(img, {"width": sw // 2, "height": sh // 2, "filter": "cubic"})
+                    name = N.lib().picha_hip_last_kernel().decode()
+                    assert max_code_diff(got, exp7) == 0, (sw, sh, per_lane, chunks, name)
+
+
+def test_resize_fma_numerics_streaming_kernel():
+    rng = np.random.default_rng(78)
+    for per_lane in (1, 2, 4):
+        img = rand_image(rng, 640, 480, "rgba")
+        exp = oracle_resize(img, 320, 240, "cubic", 0.70)
+        set_opt("numerics", 1)
+        set_opt("per_lane", per_lane)
+        got = picha_amd.resizeSync(img, {"width": 320, "height": 240})
+        name = N.lib().picha_hip_last_kernel().decode()
+        assert name.startswith("resize_stream") and "fma" in name, name
+        assert max_code_diff(got, exp) <= 1, name
 
 
 def test_resize_fma_numerics_within_one_code_value():
