@@ -78,6 +78,10 @@ def main():
     ap.add_argument("--workload", default="cfg2_4k_rgba_to_1080p_cubic", choices=sorted(WORKLOADS))
     ap.add_argument("--images", type=int, default=0, help="override images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--numerics", choices=["fma", "exact"], default="exact",
+                    help="fma: fused multiply-add flavour, <= 1 code value from the reference (the north star's "
+                         "tolerance for the float-accumulated resample filters); exact: the reference's unfused "
+                         "arithmetic, bit-identical output.  The other flavour is timed too and reported beside it.")
     ap.add_argument("--option", action="append", default=[], help="library knob key=value (e.g. row_chunks=4)")
     args = ap.parse_args()
 
@@ -101,9 +105,14 @@ def main():
     from picha_amd import _native as N
     from picha_amd.device import DeviceBatch, ResizePlan
 
+    def set_opt(k, v):
+        N.check(N.lib().picha_hip_set_option(k.encode(), int(v)))
+
+    set_opt("numerics", 1 if args.numerics == "fma" else 0)
     for kv in args.option:
         k, v = kv.split("=")
-        N.check(N.lib().picha_hip_set_option(k.encode(), int(v)))
+        set_opt(k, v)
+    numerics = "fma" if N.lib().picha_hip_get_option(b"numerics") == 1 else "exact"
 
     n, sw, sh, pixel, dw, dh, opts = WORKLOADS[args.workload]
     if args.images:
@@ -141,6 +150,27 @@ def main():
     launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     avg_launch_ms = sum(launch_ms) / len(launch_ms)
 
+    # the other numerics flavour, timed the same way on rank 0's batch (reported, not the headline)
+    other = None
+    if rank == 0 and world == 1:
+        other_name = "exact" if numerics == "fma" else "fma"
+        set_opt("numerics", 1 if other_name == "fma" else 0)
+        for _ in range(max(1, args.warmup)):
+            plan.run()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(args.steps):
+            plan.run()
+        e1.record()
+        torch.cuda.synchronize()
+        oms = e0.elapsed_time(e1) / args.steps
+        other = {"numerics": other_name, "kernel": N.lib().picha_hip_last_kernel().decode(), "avg_launch_ms": round(oms, 4)}
+        other_img0 = dst.image_host(0)
+        set_opt("numerics", 1 if numerics == "fma" else 0)
+        plan.run()  # leave dst holding the headline flavour's output for the parity sample below
+        torch.cuda.synchronize()
+
     # parity sample: first image of this rank's batch against the oracle (the checker, not the product)
     parity = None
     if rank == 0 and not args.no_cpu_baseline:
@@ -155,6 +185,8 @@ def main():
         a = got.pixels().astype(np.int64)
         b = picha_amd.Image(width=dw, height=dh, pixel=pixel, data=exp).pixels().astype(np.int64)
         parity = int(np.abs(a - b).max())
+        if other is not None:
+            other["parity_max_code_diff_vs_oracle_image0"] = int(np.abs(other_img0.pixels().astype(np.int64) - b).max())
 
     if rank == 0:
         bpp = N.PIXEL_BYTES[pixel]
@@ -189,6 +221,8 @@ def main():
                             % (args.workload, n, sw, sh, pixel, dw, dh, json.dumps(opts)),
                 "images_per_gpu": n,
                 "kernel": kernel,
+                "numerics": numerics + (" (fused multiply-add; bar: <= 1 code value from the reference)" if numerics == "fma"
+                                        else " (reference arithmetic; bar: bit-identical)"),
                 "parallelism": "image-sharded x%d" % world,
                 "dst_mpix_per_s": round(n * dw * dh * world * args.steps / elapsed / 1e6, 1),
                 "parity_max_code_diff_vs_oracle_image0": parity,
@@ -206,6 +240,10 @@ def main():
                 "read_only_frac": round(read_b / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
         }
+        if other is not None:
+            other["value_mpix_s"] = round(src_px / (other["avg_launch_ms"] * 1e-3) / 1e6, 1)
+            other["roofline_frac"] = round(alg_bytes / (other["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            out["other_numerics"] = other
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))

@@ -57,7 +57,12 @@ bool valid_pixel(int p) { return p >= 0 && p < PICHA_NUM_PIXELS; }
 std::mutex g_opt_mu;
 long g_opt_path = 0;        // 0 auto, 1 two-pass, 2 fused (error if unsupported), 3 fused but never the streaming kernel
 long g_opt_row_chunks = 0;  // 0 auto
-long g_opt_numerics = 0;    // 0 reference arithmetic (bit-exact), 1 fused-multiply-add flavour (<= 1 code value)
+// 0 reference arithmetic (bit-exact, the default), 1 fused-multiply-add flavour (<= 1 code value).
+// PICHA_HIP_NUMERICS=fma|exact in the environment sets the initial value.
+long g_opt_numerics = [] {
+    const char *e = getenv("PICHA_HIP_NUMERICS");
+    return (e && strcmp(e, "fma") == 0) ? 1L : 0L;
+}();
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 
 // ---- per-device state ---------------------------------------------------------------------------
@@ -435,10 +440,12 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (fused_ok && opt_path != 1 && opt_path != 3) {
         const int sx = std::max(1, (int)std::lround((double)s0.width / d0.width));
         const int sy = std::max(1, (int)std::lround((double)s0.height / d0.height));
-        static const int cand_s[] = {2, 1, 4};
+        // measured on MI355X (interleaved A/B, cfg2): reference arithmetic is fastest with 2 outputs per
+        // lane (fewer conversions per output), the fma flavour with 1 (more waves in flight)
+        const int cand_s[] = {fma ? 1 : 2, fma ? 2 : 1, 4};
         for (int pl : cand_s) {
             if (opt_per_lane > 0 && pl != opt_per_lane) continue;
-            if (opt_per_lane == 0 && pl != 2) continue;
+            if (opt_per_lane == 0 && pl == 4) continue;
             if (!stream_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps)) continue;
             const DeviceAxis::XTable *cx = nullptr;
             const DeviceAxis::YStream *cy = nullptr;

@@ -1,0 +1,27 @@
+"""Interleaved A/B of kernel options in one process (box-to-box and warm-up effects cancel)."""
+import sys, json, itertools
+sys.path.insert(0, '.')
+import torch
+from picha_amd import _native as N
+from picha_amd.device import DeviceBatch, ResizePlan
+def opt(k, v): N.check(N.lib().picha_hip_set_option(k.encode(), v))
+torch.cuda.set_device(0)
+src = DeviceBatch(256, 3840, 2160, 'rgba').fill_random(1)
+dst = DeviceBatch(256, 1920, 1080, 'rgba')
+plan = ResizePlan(src, dst)
+variants = [dict(numerics=n, per_lane=p, path=pa) for n in (0, 1) for (p, pa) in ((2, 2), (1, 2), (4, 2), (2, 3))]
+if len(sys.argv) > 1:
+    variants = json.loads(sys.argv[1])
+res = {}
+for rnd in range(4):
+    for v in variants:
+        for k, x in v.items(): opt(k, x)
+        plan.run(); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10): plan.run()
+        e1.record(); torch.cuda.synchronize()
+        name = N.lib().picha_hip_last_kernel().decode() + ' ' + json.dumps({k: x for k, x in v.items() if k not in ('numerics', 'per_lane', 'path')})
+        res.setdefault(name, []).append(e0.elapsed_time(e1) / 10)
+for k, v in res.items():
+    print('%-62s %s  min %.3f' % (k, ' '.join('%.3f' % x for x in v), min(v)))
