@@ -1,0 +1,122 @@
+"""The C-ABI library: every symbol include/picha_hip.h declares is exported, the product does not
+link the oracle, and the reference-arithmetic kernels contain no fused multiply-add.  No GPU needed."""
+import ctypes
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+from picha_amd import _native as N
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "picha_hip.h")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(picha_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 25
+    L = ctypes.CDLL(N.SO_PATH)
+    for n in names:
+        assert hasattr(L, n), "libpicha_hip.so does not export %s" % n
+    # and the Python binding covers the same set (a stale binding would hide an ABI change)
+    bound = sorted(n for n, _, _ in N.SYMBOLS)
+    assert bound == names
+
+
+def test_cheap_calls_work_without_a_gpu():
+    L = N.lib()
+    assert [L.picha_pixel_bytes(i) for i in range(8)] == [3, 4, 1, 2, 2, 4, 6, 8]
+    assert [L.picha_pixel_channels(i) for i in range(8)] == [3, 4, 1, 2, 1, 2, 3, 4]
+    assert L.picha_pixel_bytes(8) == 0 and L.picha_pixel_bytes(-1) == 0
+    assert L.picha_row_stride(5, 0) == 16 and L.picha_row_stride(1920, 1) == 7680
+    for i, name in enumerate(N.PIXELS):
+        assert L.picha_pixel_from_name(name.encode()) == i and L.picha_pixel_name(i).decode() == name
+    assert L.picha_pixel_from_name(b"bgr") == -1
+    for i, name in enumerate(N.FILTERS):
+        assert L.picha_filter_from_name(name.encode()) == i and L.picha_filter_name(i).decode() == name
+    assert L.picha_hip_strerror(-1).decode() == "invalid image"
+    assert L.picha_hip_strerror(-2).decode() == "invalid dimensions"
+    assert L.picha_hip_set_option(b"no_such_knob", 1) != 0
+    assert L.picha_hip_device_count() >= 0
+
+
+def test_product_does_not_link_or_load_the_oracle():
+    out = subprocess.run(["ldd", N.SO_PATH], capture_output=True, text=True).stdout
+    assert "oracle" not in out
+    syms = subprocess.run(["nm", "-D", "--defined-only", N.SO_PATH], capture_output=True, text=True).stdout
+    assert "oracle_" not in syms
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "picha_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".js", ".c")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "import oracle" not in text and "libpicha_oracle" not in text and "picha_oracle.h" not in text, f
+
+
+FUSED = re.compile(r"\b(v_fma_f32|v_fmac_f32|v_pk_fma_f32|v_mad_f32|v_mac_f32|v_fma_mix|v_fma_legacy|v_dot)")
+
+
+@pytest.fixture(scope="module")
+def device_disassembly(tmp_path_factory):
+    if not (os.path.exists(LLVM + "/clang-offload-bundler") and shutil.which("objcopy")):
+        pytest.skip("LLVM tools not available")
+    d = tmp_path_factory.mktemp("isa")
+    fat, co = str(d / "fat.bin"), str(d / "dev.co")
+    # NB: objcopy with a single file argument rewrites that file in place — fatal for a library this
+    # very process has mapped.  Always give it a throw-away output file.
+    subprocess.check_call(["objcopy", "--dump-section", ".hip_fatbin=" + fat, N.SO_PATH, str(d / "discard.so")])
+    subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                           "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+    # stream the disassembly (~2M lines): keep only per-function facts
+    proc = subprocess.Popen([LLVM + "/llvm-objdump", "-d", co], stdout=subprocess.PIPE, text=True)
+    funcs = {}
+    cur = None
+    head = re.compile(r"^[0-9a-f]+ <(\S+)>:")
+    for line in proc.stdout:
+        m = head.match(line)
+        if m:
+            cur = funcs.setdefault(m.group(1), {"lines": 0, "fused": [], "scratch": 0})
+        elif cur is not None and line.strip():
+            cur["lines"] += 1
+            if FUSED.search(line) and len(cur["fused"]) < 3:
+                cur["fused"].append(line.strip())
+            if "scratch_" in line:
+                cur["scratch"] += 1
+    assert proc.wait() == 0
+    return funcs
+
+
+
+
+def test_reference_arithmetic_kernels_have_no_fused_multiply_add(device_disassembly):
+    """the canonical numerics are unfused.  Every kernel except the explicit fma flavour
+    (template flag FMA == true) must be free of fused multiply-add instructions."""
+    funcs = device_disassembly
+    kernels = {k: v for k, v in funcs.items() if "picha_hip" in k and "kernel" in k}
+    assert len(kernels) > 100
+    checked = fma_flavour = 0
+    for name, body in kernels.items():
+        m = re.search(r"resize_(?:span|stream)_kernelI.*ELb([01])EEEvNS_", name)
+        if m and m.group(1) == "1":
+            fma_flavour += 1
+            assert body["fused"], "fma flavour without fma? " + name
+            continue
+        checked += 1
+        assert not body["fused"], "%s contains fused multiply-add: %s" % (name, body["fused"])
+    assert checked > 100 and fma_flavour > 10
+
+
+def test_kernels_are_gfx950_wave64_without_scratch_spills(device_disassembly):
+    funcs = device_disassembly
+    hot = [k for k in funcs if "resize_stream_kernel" in k or "color_convert_kernel" in k]
+    assert hot
+    for k in hot:
+        assert funcs[k]["scratch"] == 0, "scratch traffic in " + k
