@@ -1,0 +1,144 @@
+"use strict";
+// Plain-node test runner (mocha is not installed here).  Mirrors the reference's specs for the hot
+// path — test/color_convert.js, test/resize.js, test/copy.js — with the decoded fixture pixels read
+// from tests/golden/*.npy instead of going through the (out-of-scope) codecs.
+//   node test/run.js         argument/Image tests always; device tests when a GPU is present
+const assert = require('assert');
+const fs = require('fs');
+const path = require('path');
+const picha = require('../index.js');
+const Image = picha.Image;
+
+const GOLDEN = path.join(__dirname, '..', '..', '..', 'tests', 'golden');
+let failures = 0, ran = 0, pending = 0;
+
+function test(name, fn) {
+	ran += 1;
+	try {
+		const r = fn(function done(err) { pending -= 1; if (err) { failures += 1; console.log('FAIL', name, err); } finish(); });
+		if (fn.length === 0) console.log('ok  ', name);
+		else { pending += 1; console.log('ok  ', name, '(async started)'); }
+		return r;
+	} catch (e) { failures += 1; console.log('FAIL', name, e && e.stack || e); }
+}
+function finish() {
+	if (pending === 0) { console.log(failures ? 'FAILED ' + failures : 'all ' + ran + ' passed'); process.exitCode = failures ? 1 : 0; }
+}
+function throwsMsg(fn, msg) {
+	try { fn(); } catch (e) { assert.strictEqual(e.message, msg); return; }
+	assert.fail('expected throw: ' + msg);
+}
+// minimal .npy reader (v1/v2, C order, |u1)
+function npy(name) {
+	const b = fs.readFileSync(path.join(GOLDEN, name));
+	assert.strictEqual(b.toString('latin1', 1, 6), 'NUMPY');
+	const hlen = b[6] === 1 ? b.readUInt16LE(8) : b.readUInt32LE(8);
+	const off = (b[6] === 1 ? 10 : 12) + hlen;
+	const header = b.toString('latin1', b[6] === 1 ? 10 : 12, off);
+	assert(/'descr': '\|u1'/.test(header), header);
+	const shape = /'shape': \(([^)]*)\)/.exec(header)[1].split(',').filter(s => s.trim()).map(Number);
+	return { shape, data: b.slice(off) };
+}
+
+// ---- Image (reference lib/image.js, test/copy.js) ---------------------------------------------
+test('Image defaults, zero fill, stride rounding', () => {
+	const im = new Image({ width: 5, height: 3 });
+	assert.strictEqual(im.pixel, 'rgba'); assert.strictEqual(im.stride, 20); assert.strictEqual(im.data.length, 60);
+	assert(im.data.every(v => v === 0));
+	assert.strictEqual(new Image({ width: 5, height: 3, pixel: 'rgb' }).stride, 16);
+	assert.strictEqual(Image.pixelSize('r16g16b16a16'), 8); assert.strictEqual(Image.pixelSize('nope'), 0);
+});
+test('Image constructor errors', () => {
+	throwsMsg(() => new Image({ width: 2, height: 2, pixel: 'bgr' }), 'invalid pixel format bgr');
+	throwsMsg(() => new Image({ width: 4, height: 2, stride: 8 }), 'stride too short');
+	throwsMsg(() => new Image({ width: 4, height: 2, data: Buffer.alloc(8) }), 'image data too small');
+});
+test('copy / subView / equalPixels (reference test/copy.js:17-21)', () => {
+	const src = npy('test2_rgb.npy');
+	const image = new Image({ width: 76, height: 50, pixel: 'rgb', data: Buffer.from(src.data) });
+	const c = new Image({ width: 30, height: 30, pixel: image.pixel });
+	image.copy(c);
+	assert(image.subView(0, 0, 30, 30).equalPixels(c));
+	assert.strictEqual(image.avgChannelDiff(image), 0);
+	assert.strictEqual(image.avgChannelDiff(c), 255);
+});
+
+// ---- argument checks: the reference's messages (src/resize.cc, src/colorconvert.cc) -------------
+test('argument errors', () => {
+	const img = new Image({ width: 4, height: 4 });
+	throwsMsg(() => picha.resizeSync(img), 'expected: resizeSync(image, opts)');
+	throwsMsg(() => picha.resizeSync(3, {}), 'expected: resizeSync(image, opts)');
+	// the facade always hands the addon a function (as the reference's index.js:13-17 does), so a bad
+	// callback surfaces at the addon only when it is called directly
+	const native = require('../build/Release/picha.node');
+	throwsMsg(() => native.resize(img, {}, 5), 'expected: resize(image, opts, cb)');
+	throwsMsg(() => native.resize(img, {}), 'expected: resize(image, opts, cb)');
+	throwsMsg(() => native.colorConvert(img, {}, null), 'expected: colorConvert(image, opts, cb)');
+	throwsMsg(() => picha.resize(img, {}, 5), 'invalid dimensions');
+	throwsMsg(() => picha.colorConvertSync(img), 'expected: colorConvertSync(image, opts)');
+	throwsMsg(() => picha.colorConvert(img, {}, null), 'expected pixel mode');
+	throwsMsg(() => picha.resizeSync({ width: 4, height: 4, stride: 16, pixel: 'rgba' }, { width: 2, height: 2 }), 'invalid image');
+	throwsMsg(() => picha.resizeSync({ width: 4, height: 4, stride: 16, pixel: 'rgba', data: [1, 2] }, { width: 2, height: 2 }), 'invalid image');
+	throwsMsg(() => picha.resizeSync({ width: 4, height: 4, stride: 16, pixel: 'rgba', data: Buffer.alloc(10) }, { width: 2, height: 2 }), 'invalid image');
+	throwsMsg(() => picha.resizeSync(img, { width: 0, height: 2 }), 'invalid dimensions');
+	throwsMsg(() => picha.resizeSync(img, { height: 2 }), 'invalid dimensions');
+	throwsMsg(() => picha.resizeSync(img, { width: 2147483648, height: 2 }), 'invalid dimensions');
+	throwsMsg(() => picha.resizeSync(img, { width: 2, height: 2, filter: 'nope' }), 'invalid filter mode');
+	throwsMsg(() => picha.resizeSync(img, { width: 2, height: 2, filter: 1 }), 'invalid filter mode');
+	throwsMsg(() => picha.resizeSync(img, { width: 2, height: 2, filterScale: 0 }), 'invalid filter width');
+	throwsMsg(() => picha.resizeSync(img, { width: 2, height: 2, filterScale: 'wide' }), 'invalid filter width');
+	throwsMsg(() => picha.colorConvertSync(img, {}), 'expected pixel mode');
+	throwsMsg(() => picha.colorConvertSync(img, { pixel: 'cmyk' }), 'expected pixel mode');
+	assert.deepStrictEqual(Object.keys(picha.catalog), []);
+});
+
+const haveGpu = picha.hipDeviceCount() > 0;
+if (!haveGpu) {
+	test('no device: the path fails loudly (no CPU fallback)', () => {
+		const img = new Image({ width: 8, height: 8 });
+		assert.throws(() => picha.resizeSync(img, { width: 4, height: 4 }), /no HIP device/);
+		assert.throws(() => picha.colorConvertSync(img, { pixel: 'grey' }), /no HIP device/);
+	});
+} else {
+	const rgbaPx = npy('test_rgba.npy'), greyPx = npy('greytest_greya.npy'), srcPx = npy('test2_rgb.npy'), smallPx = npy('test2_small_rgb.npy');
+	const rgbImage = new Image({ width: 50, height: 50, pixel: 'rgba', data: Buffer.from(rgbaPx.data) });
+	const greyImage = new Image({ width: 50, height: 50, pixel: 'greya', data: Buffer.from(greyPx.data) });
+	test('color_convert: conversion to grey should match (reference test/color_convert.js:22-29)', () => {
+		const toGrey = picha.colorConvertSync(rgbImage, { pixel: 'greya' });
+		assert.strictEqual(toGrey.pixel, 'greya'); assert.strictEqual(toGrey.width, 50); assert.strictEqual(toGrey.height, 50);
+		assert(toGrey.equalPixels(greyImage));
+	});
+	test('color_convert: grey-color-grey should be invariant (reference test/color_convert.js:30-40)', (done) => {
+		picha.colorConvert(greyImage, { pixel: 'rgba' }, (err, img) => {
+			if (err) return done(err);
+			picha.colorConvert(img, { pixel: greyImage.pixel }, (err2, rimg) => {
+				if (err2) return done(err2);
+				try { assert(greyImage.equalPixels(rimg)); done(); } catch (e) { done(e); }
+			});
+		});
+	});
+	const image = new Image({ width: 76, height: 50, pixel: 'rgb', data: Buffer.from(srcPx.data) });
+	const smallImage = new Image({ width: 32, height: 24, pixel: 'rgb', data: Buffer.from(smallPx.data) });
+	test('resize: async then sync (reference test/resize.js:20-31)', (done) => {
+		picha.resize(image, { width: 32, height: 24 }, (err, asyncSmall) => {
+			if (err) return done(err);
+			try {
+				assert(asyncSmall.avgChannelDiff(smallImage) < 2);
+				assert(asyncSmall.equalPixels(smallImage));   // stronger than the reference's bound
+				const syncSmall = picha.resizeSync(image, { width: 32, height: 24 });
+				assert(syncSmall.avgChannelDiff(smallImage) < 2);
+				assert(syncSmall.equalPixels(asyncSmall));
+				done();
+			} catch (e) { done(e); }
+		});
+	});
+	test('resize: every filter and a 16-bit format run', () => {
+		const big = new Image({ width: 64, height: 48, pixel: 'r16g16b16a16' });
+		for (let i = 0; i < big.data.length; ++i) big.data[i] = (i * 37 + 11) & 255;
+		for (const filter of ['cubic', 'lanczos', 'catmulrom', 'mitchel', 'box', 'triangle']) {
+			const out = picha.resizeSync(big, { width: 32, height: 24, filter });
+			assert.strictEqual(out.pixel, 'r16g16b16a16'); assert.strictEqual(out.stride, 32 * 8);
+		}
+	});
+}
+finish();
