@@ -30,6 +30,9 @@ WORKLOADS = {
     "cfg2_4k_rgba_to_1080p_cubic_scale1": (256, 3840, 2160, "rgba", 1920, 1080, {"filter": "cubic"}),
     "cfg1_640x480_rgba_to_320x240": (256, 640, 480, "rgba", 320, 240, {}),
     "cfg3b_4k_grey_to_512_lanczos": (256, 3840, 2160, "grey", 512, 512, {"filter": "lanczos"}),
+    # colour convert: dst size == src size, opts names the destination format
+    "cfg3a_4k_rgb_to_grey": (256, 3840, 2160, "rgb", 3840, 2160, {"convert": "grey"}),
+    "cc_4k_rgba_to_rgba16": (64, 3840, 2160, "rgba", 3840, 2160, {"convert": "r16g16b16a16"}),
     "cfg5_8k_rgba16_to_1080p_mitchel": (32, 7680, 4320, "r16g16b16a16", 1920, 1080, {"filter": "mitchel"}),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable copy)
@@ -118,8 +121,18 @@ def main():
     if args.images:
         n = args.images
     src = DeviceBatch(n, sw, sh, pixel, device=dev).fill_random(20250226 + 7919 * rank)
-    dst = DeviceBatch(n, dw, dh, pixel, device=dev)
-    plan = ResizePlan(src, dst, filter=opts.get("filter"), filter_scale=opts.get("filterScale"))
+    convert_to = opts.get("convert")
+    dst_pixel = convert_to or pixel
+    dst = DeviceBatch(n, dw, dh, dst_pixel, device=dev)
+    if convert_to:
+        from picha_amd.device import color_convert_batch
+
+        class _ConvertPlan:
+            def run(self):
+                color_convert_batch(src, convert_to, out=dst)
+        plan = _ConvertPlan()
+    else:
+        plan = ResizePlan(src, dst, filter=opts.get("filter"), filter_scale=opts.get("filterScale"))
     torch.cuda.synchronize()
 
     def barrier():
@@ -129,7 +142,7 @@ def main():
     for _ in range(args.warmup):
         plan.run()
     torch.cuda.synchronize()
-    kernel = N.lib().picha_hip_last_kernel().decode()
+    kernel = "color_convert_kernel<%s->%s>" % (pixel, convert_to) if convert_to else N.lib().picha_hip_last_kernel().decode()
 
     # per-launch durations from events on the launch stream (torch's current stream)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -152,7 +165,7 @@ def main():
 
     # the other numerics flavour, timed the same way on rank 0's batch (reported, not the headline)
     other = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not convert_to:
         other_name = "exact" if numerics == "fma" else "fma"
         set_opt("numerics", 1 if other_name == "fma" else 0)
         for _ in range(max(1, args.warmup)):
@@ -181,9 +194,12 @@ def main():
         got = dst.image_host(0)
         filt = opts.get("filter", "cubic")
         fscale = opts.get("filterScale", 1.0 if "filter" in opts else 0.70)
-        exp, _ = oracle.resize(img.data, sw, sh, pixel, dw, dh, filt, fscale)
+        if convert_to:
+            exp, _ = oracle.color_convert(img.data, sw, sh, pixel, convert_to)
+        else:
+            exp, _ = oracle.resize(img.data, sw, sh, pixel, dw, dh, filt, fscale)
         a = got.pixels().astype(np.int64)
-        b = picha_amd.Image(width=dw, height=dh, pixel=pixel, data=exp).pixels().astype(np.int64)
+        b = picha_amd.Image(width=dw, height=dh, pixel=dst_pixel, data=exp).pixels().astype(np.int64)
         parity = int(np.abs(a - b).max())
         if other is not None:
             other["parity_max_code_diff_vs_oracle_image0"] = int(np.abs(other_img0.pixels().astype(np.int64) - b).max())
@@ -193,7 +209,7 @@ def main():
         src_px = n * sw * sh
         total_px = src_px * world * args.steps
         read_b = n * sw * sh * bpp
-        write_b = n * dw * dh * bpp
+        write_b = n * dw * dh * N.PIXEL_BYTES[dst_pixel]
         alg_bytes = read_b + write_b
         ach = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
         traffic = None
@@ -244,7 +260,7 @@ def main():
             other["value_mpix_s"] = round(src_px / (other["avg_launch_ms"] * 1e-3) / 1e6, 1)
             other["roofline_frac"] = round(alg_bytes / (other["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             out["other_numerics"] = other
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not convert_to:
             out["cpu_baseline"] = cpu_baseline(args.workload)
         print(json.dumps(out))
     if world > 1:

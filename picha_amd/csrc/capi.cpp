@@ -238,9 +238,9 @@ int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, DeviceA
 // pixels a padded tap addresses are either inside the image (finite, times 0) or outside it (the
 // kernel's buffer loads return 0).  fma: weights pre-multiplied by 1/max of the sample type.
 int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps, int fma, int is16,
-               const DeviceAxis::XTable **out) {
+               const DeviceAxis::XTable **out, int bytespan_bpp = 0) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    auto key = std::make_tuple(per_lane, step, taps, fma, is16);
+    auto key = std::make_tuple(per_lane, step, taps, fma, is16 + 16 * bytespan_bpp);
     auto it = ax->xtables.find(key);
     if (it != ax->xtables.end()) { *out = &it->second; return PICHA_OK; }
     DeviceAxis::XTable xt;
@@ -252,9 +252,15 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
     std::vector<float> weight((size_t)taps * stride, 0.0f);
     const float inv = is16 ? 1.0f / 65535.0f : 1.0f / 255.0f;
     bool ok = taps >= T || per_lane > 1;
+    // byte-span kernels read whole dwords from the window start: the window (taps*bpp bytes, a
+    // multiple of 4) must end inside the row, so windows near the right edge are shifted left and
+    // their weights move to the back (zero weights in front leave the sum unchanged)
+    const int max_left = bytespan_bpp ? t.src_size - taps : INT32_MAX;
+    if (bytespan_bpp && max_left < 0) ok = false;
     for (int g = 0; g < groups && ok; ++g) {
         int base = INT32_MAX;
         for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) base = std::min(base, t.left[g * per_lane + q] - step * q);
+        base = std::min(base, max_left);
         left[g] = base;
         for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) {
             const int i = g * per_lane + q;
@@ -419,7 +425,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) fused_ok = false;
         if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % al) fused_ok = false;
     }
-    int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps);
+    int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps, pixel);
     const DeviceAxis::XTable *xt = nullptr;
     if (fused_ok && opt_per_lane != 1) {
         // integer decimation / interpolation step of the tap windows
@@ -497,7 +503,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (fused_ok && !xt) {
         fused_ok = ktaps > 0 && fused_supported(pixel, ktaps, ay->host.taps, ring, 1);
         if (fused_ok) {
-            rc = get_xtable(ctx, ax, 1, 1, ktaps, fma, is16, &xt);
+            rc = get_xtable(ctx, ax, 1, 1, ktaps, fma, is16, &xt, fused_x_bytespan(ktaps, pixel) ? kBytes[pixel] : 0);
             if (rc) return rc;
             fused_ok = xt->ok;
         }
