@@ -1,0 +1,132 @@
+"""BASELINE.json's full sizes on the GPU, checked through properties that do not need a CPU pass over
+the whole batch: agreement between independent kernel families on a checksum of the entire output,
+per-image independence of batched launches, constants staying constant, colour-convert round trips,
+plus an oracle spot check of single images."""
+import hashlib
+
+import numpy as np
+import pytest
+import torch
+
+import picha_amd
+from picha_amd import _native as N
+from picha_amd.device import DeviceBatch, color_convert_batch, resize_batch
+from util import oracle_convert, oracle_resize
+
+pytestmark = pytest.mark.gpu
+
+
+def set_opt(key, v):
+    N.check(N.lib().picha_hip_set_option(key.encode(), v))
+
+
+@pytest.fixture(autouse=True)
+def _reset():
+    yield
+    for k in ("path", "numerics", "per_lane", "row_chunks"):
+        set_opt(k, 0)
+
+
+def digest(batch):
+    """sha1 over the payload of every image (row padding excluded: it is never written)."""
+    h = hashlib.sha1()
+    bpp = N.PIXEL_BYTES[batch.pixel]
+    rows = batch.tensor[:, : batch.height * batch.stride].reshape(batch.n, batch.height, batch.stride)[:, :, : batch.width * bpp]
+    for i in range(batch.n):
+        h.update(rows[i].contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
+def test_cfg2_full_batch_kernel_families_agree_and_match_oracle():
+    """configs[1]: 256 x 3840x2160 rgba -> 1920x1080, picha default (cubic @ 0.70)."""
+    n = 256
+    src = DeviceBatch(n, 3840, 2160, "rgba").fill_random(20250226)
+    sums = {}
+    for path, per_lane in ((2, 2), (2, 1), (3, 2), (3, 1)):  # streaming and LDS-ring kernels, two lane layouts
+        set_opt("path", path)
+        set_opt("per_lane", per_lane)
+        out = resize_batch(src, 1920, 1080)
+        torch.cuda.synchronize()
+        sums[N.lib().picha_hip_last_kernel().decode()] = digest(out)
+    assert len(sums) == 4 and len(set(sums.values())) == 1, sums
+    # oracle spot check: first and last image of the batch (bit-exact)
+    for i in (0, n - 1):
+        exp = oracle_resize(src.image_host(i), 1920, 1080, "cubic", 0.70)
+        assert np.array_equal(out.image_host(i).pixels(), exp.pixels())
+    # batched launch == the same image resized alone through the host-pointer entry point
+    set_opt("path", 0)
+    set_opt("per_lane", 0)
+    alone = picha_amd.resizeSync(src.image_host(7), {"width": 1920, "height": 1080})
+    assert np.array_equal(alone.pixels(), out.image_host(7).pixels())
+    # two-pass scratch kernels on one full-size image
+    set_opt("path", 1)
+    two = picha_amd.resizeSync(src.image_host(7), {"width": 1920, "height": 1080})
+    assert np.array_equal(two.pixels(), alone.pixels())
+
+
+def test_cfg2_constant_images_stay_constant():
+    """Normalised taps: a constant image resamples to the same constant, for every value and filter."""
+    src = DeviceBatch(8, 3840, 2160, "rgba")
+    vals = [0, 1, 77, 128, 200, 254, 255, 31]
+    for i, v in enumerate(vals):
+        src.tensor[i].fill_(v)
+    for filt in (None, "lanczos", "mitchel"):
+        out = resize_batch(src, 1920, 1080, filter=filt)
+        torch.cuda.synchronize()
+        for i, v in enumerate(vals):
+            img = out.tensor[i, : 1080 * out.stride]
+            assert int(img.min()) == v and int(img.max()) == v, (filt, v)
+
+
+def test_cfg3_full_size_convert_then_lanczos_pipeline():
+    """configs[2]: 3840x2160 rgb -> grey colorConvert, then -> 512x512 lanczos."""
+    n = 64
+    src = DeviceBatch(n, 3840, 2160, "rgb").fill_random(3)
+    grey = color_convert_batch(src, "grey")
+    small = resize_batch(grey, 512, 512, filter="lanczos")
+    torch.cuda.synchronize()
+    for i in (0, n - 1):
+        g = oracle_convert(src.image_host(i), "grey")
+        assert np.array_equal(grey.image_host(i).pixels(), g.pixels())
+        s = oracle_resize(g, 512, 512, "lanczos", 1.0)
+        assert np.array_equal(small.image_host(i).pixels(), s.pixels())
+    # grey -> rgb -> grey is the identity (L = (v*r + v*g) + v*b with normalised weights)
+    back = color_convert_batch(color_convert_batch(grey, "rgb"), "grey")
+    torch.cuda.synchronize()
+    assert digest(back) == digest(grey)
+    # 8-bit -> 16-bit -> 8-bit is the identity too
+    wide = color_convert_batch(src, "r16g16b16")
+    narrow = color_convert_batch(wide, "rgb")
+    torch.cuda.synchronize()
+    assert digest(narrow) == digest(src)
+
+
+def test_cfg5_full_size_16bit_mitchel():
+    """configs[4] geometry: 7680x4320 r16g16b16a16 -> 1920x1080 mitchel (a few images)."""
+    n = 3
+    src = DeviceBatch(n, 7680, 4320, "r16g16b16a16").fill_random(5)
+    sums = set()
+    for path in (3, 1):
+        set_opt("path", path)
+        out = resize_batch(src, 1920, 1080, filter="mitchel")
+        torch.cuda.synchronize()
+        sums.add(digest(out))
+    assert len(sums) == 1
+    exp = oracle_resize(src.image_host(n - 1), 1920, 1080, "mitchel", 1.0)
+    assert np.array_equal(out.image_host(n - 1).pixels(), exp.pixels())
+
+
+def test_non_uniform_pitch_batches_use_pointer_tables():
+    """Images of one call that are not equally spaced in memory go through device pointer tables."""
+    import ctypes
+    a = DeviceBatch(5, 640, 480, "rgba").fill_random(11)
+    out = DeviceBatch(5, 320, 240, "rgba")
+    order = [3, 0, 4, 1, 2]  # permuted: data pointers are no longer base + i * pitch
+    S = (N.CImage * 5)(*[a.descriptors()[i] for i in order])
+    D = (N.CImage * 5)(*[out.descriptors()[i] for i in order])
+    stream = torch.cuda.current_stream().cuda_stream
+    N.check(N.lib().picha_hip_resize_device(5, S, D, 0, ctypes.c_float(0.70), stream))
+    torch.cuda.synchronize()
+    for i in range(5):
+        exp = oracle_resize(a.image_host(i), 320, 240, "cubic", 0.70)
+        assert np.array_equal(out.image_host(i).pixels(), exp.pixels())
