@@ -99,10 +99,15 @@ def main():
             print("bench.py: --gpus %d but WORLD_SIZE=%d; launch with torch.distributed.run --nproc-per-node %d"
                   % (args.gpus, world, args.gpus), file=sys.stderr)
         args.gpus = world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(1, torch.cuda.device_count())
+    dev = torch.device("cuda", local_rank % ndev)  # one rank per GPU; the modulo only matters for rehearsals on a smaller box
+    torch.cuda.set_device(dev)
+    backend = os.environ.get("PICHA_BENCH_BACKEND", "nccl")  # "nccl" == RCCL on ROCm; "gloo" to rehearse N ranks on one GPU
     if world > 1:
-        dist.init_process_group(backend="nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import picha_amd
     from picha_amd import _native as N
@@ -157,7 +162,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
@@ -216,7 +221,8 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                rec = json.load(open(tpath))
+                traffic = int(rec["hbm_bytes_per_launch"] / rec.get("images_per_launch", 256) * n)
             except Exception:
                 traffic = None
         out = {

@@ -117,13 +117,19 @@ int picha_hip_device_count(void); /* number of visible HIP devices (0 if none / 
 int picha_hip_device_arch(char *buf, size_t len);
 /*
  * Tuning / test knobs (outside the drop-in surface).  Keys:
- *   "path"      0 = auto, 1 = force the two-pass scratch kernels, 2 = force the fused kernel
- *   "row_chunks" 0 = auto, else number of row chunks per image for the fused kernel
+ *   "numerics"   0 = reference arithmetic, bit-identical results (default); 1 = fused multiply-add
+ *                flavour of the resize kernels, at most one code value from the reference
+ *                (environment: PICHA_HIP_NUMERICS=fma sets the initial value)
+ *   "path"       0 = auto, 1 = force the two-pass scratch kernels, 2 = force a fused kernel (error if
+ *                none applies), 3 = fused but never the streaming kernel (LDS-ring kernel)
+ *   "per_lane"   0 = auto, else output columns per lane for the fused kernels (1, 2, 4)
+ *   "row_chunks" 0 = auto, else number of row chunks per image for the fused kernels
  * Returns PICHA_ERR_ARGUMENT for an unknown key.
  */
 int picha_hip_set_option(const char *key, long value);
 long picha_hip_get_option(const char *key);
-/* Name of the kernel family the last resize on this thread used ("fused<...>" / "twopass"). */
+/* Name of the kernel instantiation the last resize on this thread launched
+ * ("resize_stream<...>", "resize_span<...>" or "twopass"). */
 const char *picha_hip_last_kernel(void);
 
 /* ---- the hot path: host-pointer entry points -------------------------------------------------
@@ -144,6 +150,27 @@ int picha_hip_resize_batch(int n, const picha_image *src, const picha_image *dst
                            float filter_scale);
 int picha_hip_color_convert_batch(int n, const picha_image *src, const picha_image *dst,
                                   float r_factor, float g_factor, float b_factor);
+
+/* ---- the hot path: asynchronous host-pointer entry points -----------------------------------------
+ * Replacement for the reference's worker dispatch — uv_queue_work(loop, req, UV_resize, V8_resize)
+ * (src/resize.cc:362-364) and its colour-convert twin (src/colorconvert.cc:252-254).  Instead of one
+ * image per libuv worker, requests go to a per-device dispatcher that coalesces whatever is queued
+ * into batches (one H2D / kernel launch / D2H per batch, through pinned staging, three batches in
+ * flight so staging, GPU work and copy-out overlap).
+ * Argument problems are reported synchronously through the return value, exactly like the reference's
+ * synchronous throws (src/resize.cc:336-351); otherwise the call returns PICHA_OK at once and `done`
+ * is invoked later, from a library thread, with the outcome.  src->data and dst->data must stay
+ * valid until then (the reference pins them the same way, src/resize.cc:355-357).
+ */
+typedef void (*picha_hip_done_fn)(void *user, int status, const char *error);
+int picha_hip_resize_async(const picha_image *src, const picha_image *dst, int filter,
+                           float filter_scale, picha_hip_done_fn done, void *user);
+int picha_hip_color_convert_async(const picha_image *src, const picha_image *dst, float r_factor,
+                                  float g_factor, float b_factor, picha_hip_done_fn done, void *user);
+/* Blocks until every request queued so far has completed (tests, orderly shutdown). */
+int picha_hip_async_drain(void);
+/* Number of batches the dispatcher has launched and of requests it has completed (diagnostics). */
+void picha_hip_async_stats(uint64_t *batches, uint64_t *requests);
 
 /* ---- the hot path: device-resident entry points ------------------------------------------------
  * Same operations on images whose `data` already lives in the current device's HBM.  Asynchronous:

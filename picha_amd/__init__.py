@@ -10,6 +10,7 @@ from .api import (  # noqa: F401
     colorConvert,
     colorConvertSync,
     color_settings,
+    drain,
     make_contribs,
     resize,
     resizeSync,

@@ -61,6 +61,10 @@ SYMBOLS = [
     ("picha_hip_color_convert", _i, [_P, _P, _f, _f, _f]),
     ("picha_hip_resize_batch", _i, [_i, _P, _P, _i, _f]),
     ("picha_hip_color_convert_batch", _i, [_i, _P, _P, _f, _f, _f]),
+    ("picha_hip_resize_async", _i, [_P, _P, _i, _f, _vp, _vp]),
+    ("picha_hip_color_convert_async", _i, [_P, _P, _f, _f, _f, _vp, _vp]),
+    ("picha_hip_async_drain", _i, []),
+    ("picha_hip_async_stats", None, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     ("picha_hip_resize_device", _i, [_i, _P, _P, _i, _f, _vp]),
     ("picha_hip_color_convert_device", _i, [_i, _P, _P, _f, _f, _f, _vp]),
     ("picha_hip_malloc", _i, [ctypes.POINTER(_vp), _sz]),
@@ -71,6 +75,8 @@ SYMBOLS = [
     ("picha_hip_fill_random", _i, [_vp, _sz, ctypes.c_uint64, _i, _vp]),
     ("picha_fill_random_host", None, [_vp, _sz, ctypes.c_uint64, _i]),
 ]
+
+DONE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p)
 
 _lib = None
 

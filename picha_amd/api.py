@@ -4,15 +4,16 @@
     colorConvert(image, opts, cb) / colorConvertSync(image, opts)  reference index.js:25-33, src/colorconvert.cc:215-291
 
 Same option names and semantics, same error strings; results are `Image` objects.  The async
-variants run the C-ABI call on a worker pool and deliver `cb(None, image)` (the reference's
-callbacks likewise never receive an error for argument problems — those throw synchronously,
-SURVEY.md quirk 7; a device failure, a class of error the reference does not have, is delivered
-as cb(err, None)).
+variants hand the request to the library's batching dispatcher (picha_hip_*_async) and deliver
+`cb(None, image)` from a library thread (the reference's callbacks likewise never receive an error
+for argument problems — those throw synchronously; a device failure, a class of
+error the reference does not have, is delivered as cb(err, None)).
 """
-import concurrent.futures
 import ctypes
+import itertools
 import math
 import numbers
+import threading
 
 import numpy as np
 
@@ -21,15 +22,40 @@ from .image import Image
 
 PichaError = N.PichaError
 
-_pool = None
+# Async calls go to the library's batching dispatcher (picha_hip_*_async: the replacement for the
+# reference's uv_queue_work dispatch, src/resize.cc:362-364).  Until a request completes, its source
+# buffer, destination image and callback trampoline are pinned here — the reference pins the same
+# three things with Persistent handles (src/resize.cc:355-357).
+_pending = {}
+_pending_lock = threading.Lock()
+_tokens = itertools.count(1)
 
 
-def _executor():
-    global _pool
-    if _pool is None:
-        # the reference dispatches to libuv's pool, default 4 threads (src/resize.cc:362-364)
-        _pool = concurrent.futures.ThreadPoolExecutor(max_workers=4, thread_name_prefix="picha")
-    return _pool
+def _submit_async(submit, src, dst, cb):
+    """submit(done_ptr) -> status.  Calls cb(None, dst) or cb(err, None) from a library thread."""
+    token = next(_tokens)
+
+    def _done(user, status, err):
+        with _pending_lock:
+            _pending.pop(token, None)
+        if status == 0:
+            cb(None, dst)
+        else:
+            cb(PichaError((err or b"").decode() or N.lib().picha_hip_strerror(status).decode(), status), None)
+
+    c_done = N.DONE_FN(_done)
+    with _pending_lock:
+        _pending[token] = (c_done, src, dst)
+    rc = submit(ctypes.cast(c_done, ctypes.c_void_p))
+    if rc != 0:
+        with _pending_lock:
+            _pending.pop(token, None)
+        N.check(rc)
+
+
+def drain():
+    """Wait for every queued async request (tests, shutdown)."""
+    N.check(N.lib().picha_hip_async_drain())
 
 
 def _get(obj, key):
@@ -140,16 +166,10 @@ def resize(image, opts, cb):
     if not callable(cb):
         raise PichaError("expected: resize(image, opts, cb)")
     src, dst, ftag, fscale = _prepare_resize(image, opts, "expected: resize(image, opts, cb)")
-
-    def work():
-        try:
-            out = _run_resize(src, dst, ftag, fscale)
-        except Exception as e:  # device failure: not a class of error the reference has
-            cb(e, None)
-            return
-        cb(None, out)
-
-    return _executor().submit(work)
+    cdst = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index(dst.pixel))
+    L = N.lib()
+    _submit_async(lambda done: L.picha_hip_resize_async(ctypes.byref(src[0]), ctypes.byref(cdst), ftag, fscale, done, None),
+                  src, dst, cb)
 
 
 def _color_settings(opts):
@@ -194,16 +214,10 @@ def colorConvert(image, opts, cb):
     if not callable(cb):
         raise PichaError("expected: colorConvert(image, opts, cb)")
     src, dst, cs = _prepare_convert(image, opts, "expected: colorConvert(image, opts, cb)")
-
-    def work():
-        try:
-            out = _run_convert(src, dst, cs)
-        except Exception as e:
-            cb(e, None)
-            return
-        cb(None, out)
-
-    return _executor().submit(work)
+    cdst = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index(dst.pixel))
+    L = N.lib()
+    _submit_async(lambda done: L.picha_hip_color_convert_async(ctypes.byref(src[0]), ctypes.byref(cdst), cs[0], cs[1], cs[2],
+                                                               done, None), src, dst, cb)
 
 
 # ---- helpers exposed for tests / tools ----------------------------------------------------------

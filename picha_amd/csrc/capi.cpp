@@ -920,6 +920,24 @@ int picha_hip_color_convert_device(int n, const picha_image *src, const picha_im
     return PICHA_OK;
 }
 
+// Validation of one host-pointer request (shared with the asynchronous dispatcher, dispatch.cpp).
+// Not part of the public header.
+int picha_hip_validate_host_op(int is_resize, const picha_image *src, const picha_image *dst, int filter,
+                               float filter_scale, int *device) {
+    int rc = check_src(src);
+    if (rc) return rc;
+    rc = check_dst(dst);
+    if (rc) return rc;
+    if (is_resize) {
+        if (filter < 0 || filter >= PICHA_NUM_FILTERS) return fail(PICHA_ERR_INVALID_FILTER, "invalid filter mode");
+        if (!(filter_scale > 0)) return fail(PICHA_ERR_INVALID_FILTER_WIDTH, "invalid filter width");
+        if (src->pixel != dst->pixel) return fail(PICHA_ERR_PIXEL_MISMATCH, "resize: source and destination pixel formats differ");
+    } else if (src->width != dst->width || src->height != dst->height) {
+        return fail(PICHA_ERR_PIXEL_MISMATCH, "colorConvert: source and destination sizes differ");
+    }
+    return current_device(device);
+}
+
 // ---- host-pointer entry points --------------------------------------------------------------------
 int picha_hip_resize(const picha_image *src, const picha_image *dst, int filter, float filter_scale) {
     return run_host(Op::Resize, 1, src, dst, filter, filter_scale, 0, 0, 0);

@@ -10,8 +10,9 @@
  *   width/height via Uint32 -> int, must be > 0   src/resize.cc:341-346
  *   option parsing (getResizeOptions/getSettings) src/resize.cc:179-198; src/colorconvert.cc:6-22  (in the C ABI)
  *   result object (newJsImage)                    src/picha.cc:119-133
- *   async: work on a worker thread, cb(undefined, image) on the loop thread, source buffer / result /
- *   callback pinned for the duration              src/resize.cc:353-364, 296-319
+ *   async: the request goes to the library's batching dispatcher (picha_hip_*_async, the replacement for
+ *   uv_queue_work), cb(undefined, image) runs on the loop thread via a threadsafe function, source buffer /
+ *   result / callback pinned for the duration     src/resize.cc:353-364, 296-319
  * Deviations: resizeSync returns after throwing (the reference falls through); a device
  * failure — a class of error the reference does not have — is thrown (sync) or passed as cb(err).
  */
@@ -142,8 +143,8 @@ typedef struct op_ctx {
     float filter_scale;
     float cs[3];
     /* async only */
-    napi_async_work work;
-    napi_ref src_ref, dst_ref, cb_ref;
+    napi_threadsafe_function tsfn;
+    napi_ref src_ref, dst_ref;
     int status;
     char error[512];
 } op_ctx;
@@ -158,16 +159,23 @@ static void run_op(op_ctx *c) {
     }
 }
 
-static void async_execute(napi_env env, void *data) {
-    (void)env;
-    run_op((op_ctx *)data); /* worker thread: the reference's UV_resize / UV_colorConvert */
+/* completion on the library's completer thread: hop to the loop thread through the threadsafe function */
+static void async_done(void *user, int status, const char *error) {
+    op_ctx *c = (op_ctx *)user;
+    c->status = status;
+    if (status != PICHA_OK) {
+        strncpy(c->error, (error && *error) ? error : picha_hip_strerror(status), sizeof c->error - 1);
+        c->error[sizeof c->error - 1] = 0;
+    }
+    napi_call_threadsafe_function(c->tsfn, c, napi_tsfn_blocking);
 }
 
-static void async_complete(napi_env env, napi_status st, void *data) {
+/* loop thread: the reference's V8_resize / V8_colorConvert (src/resize.cc:296-319) */
+static void async_call_js(napi_env env, napi_value cb, void *context, void *data) {
     op_ctx *c = (op_ctx *)data;
-    napi_value cb, dst, global, argv[2], result;
-    (void)st;
-    napi_get_reference_value(env, c->cb_ref, &cb);
+    napi_value dst, global, argv[2], result;
+    (void)context;
+    if (env == NULL) { free(c); return; } /* environment is shutting down */
     napi_get_reference_value(env, c->dst_ref, &dst);
     napi_get_global(env, &global);
     if (c->status == PICHA_OK) {
@@ -181,11 +189,11 @@ static void async_complete(napi_env env, napi_status st, void *data) {
     }
     napi_delete_reference(env, c->src_ref);
     napi_delete_reference(env, c->dst_ref);
-    napi_delete_reference(env, c->cb_ref);
-    napi_delete_async_work(env, c->work);
+    napi_threadsafe_function tsfn = c->tsfn;
     free(c);
     /* an exception thrown by the callback propagates as an uncaught exception (reference: FatalException) */
     napi_call_function(env, global, cb, 2, argv, &result);
+    napi_release_threadsafe_function(tsfn, napi_tsfn_release);
 }
 
 /* Parses (image, opts) for either op.  Returns 0 and leaves a pending JS exception on failure. */
@@ -267,18 +275,30 @@ static napi_value do_async(napi_env env, napi_callback_info info, int is_resize,
     c->is_resize = is_resize;
     napi_value src_data = NULL, dst = NULL, name, undef;
     if (!prepare(env, argv[0], argv[1], c, &src_data, &dst)) { free(c); return NULL; }
-    /* pin the source Buffer, the result image and the callback until completion (src/resize.cc:355-357) */
+    /* pin the source Buffer and the result image until completion (src/resize.cc:355-357); the callback is
+       held by the threadsafe function */
     napi_create_reference(env, src_data, 1, &c->src_ref);
     napi_create_reference(env, dst, 1, &c->dst_ref);
-    napi_create_reference(env, argv[2], 1, &c->cb_ref);
     napi_create_string_utf8(env, "picha", NAPI_AUTO_LENGTH, &name); /* Nan::AsyncResource("picha") */
-    if (napi_create_async_work(env, NULL, name, async_execute, async_complete, c, &c->work) != napi_ok ||
-        napi_queue_async_work(env, c->work) != napi_ok) {
+    if (napi_create_threadsafe_function(env, argv[2], NULL, name, 0, 1, NULL, NULL, NULL, async_call_js, &c->tsfn) != napi_ok) {
         napi_delete_reference(env, c->src_ref);
         napi_delete_reference(env, c->dst_ref);
-        napi_delete_reference(env, c->cb_ref);
         free(c);
-        return throw_msg(env, "could not queue work");
+        return throw_msg(env, "could not create threadsafe function");
+    }
+    /* hand the request to the library's batching dispatcher (replaces uv_queue_work, src/resize.cc:362-364) */
+    int rc = c->is_resize ? picha_hip_resize_async(&c->src, &c->dst, c->filter, c->filter_scale, async_done, c)
+                          : picha_hip_color_convert_async(&c->src, &c->dst, c->cs[0], c->cs[1], c->cs[2], async_done, c);
+    if (rc != PICHA_OK) { /* rejected synchronously, e.g. no device: throw like every other argument problem */
+        char msg[512];
+        const char *m = picha_hip_last_error();
+        strncpy(msg, (m && *m) ? m : picha_hip_strerror(rc), sizeof msg - 1);
+        msg[sizeof msg - 1] = 0;
+        napi_delete_reference(env, c->src_ref);
+        napi_delete_reference(env, c->dst_ref);
+        napi_release_threadsafe_function(c->tsfn, napi_tsfn_abort);
+        free(c);
+        return throw_msg(env, msg);
     }
     napi_get_undefined(env, &undef);
     return undef;

@@ -261,3 +261,58 @@ def test_resize_fma_numerics_within_one_code_value():
                 assert d <= 1, (pixel, sw, sh, dw, dh, filt, d, name)
     # the flavour must actually have been exercised
     assert "fma" in name
+
+
+# ---- asynchronous batching dispatcher (replacement for the reference's uv_queue_work dispatch) ----------
+def test_async_dispatcher_batches_mixed_requests_and_matches_sync():
+    import threading
+    rng = np.random.default_rng(314)
+    jobs = []
+    for i in range(120):
+        kind = i % 3
+        if kind == 0:
+            img = rand_image(rng, 64 + (i % 5) * 8, 48, "rgba")
+            jobs.append(("resize", img, {"width": img.width // 2, "height": 24}))
+        elif kind == 1:
+            img = rand_image(rng, 50, 40, ["rgb", "grey", "r16g16b16a16"][i % 3 if i % 3 < 3 else 0])
+            jobs.append(("resize", img, {"width": 23, "height": 17, "filter": "lanczos"}))
+        else:
+            img = rand_image(rng, 31, 9, "rgba")
+            jobs.append(("convert", img, {"pixel": ["greya", "rgb", "r16g16b16"][i % 3]}))
+    results = [None] * len(jobs)
+    done = threading.Semaphore(0)
+
+    def make_cb(k):
+        def cb(err, out):
+            results[k] = (err, out)
+            done.release()
+        return cb
+
+    before_b, before_r = ctypes.c_uint64(), ctypes.c_uint64()
+    N.lib().picha_hip_async_stats(ctypes.byref(before_b), ctypes.byref(before_r))
+    for k, (kind, img, opts) in enumerate(jobs):
+        (picha_amd.resize if kind == "resize" else picha_amd.colorConvert)(img, opts, make_cb(k))
+    for _ in jobs:
+        assert done.acquire(timeout=120)
+    picha_amd.drain()
+    after_b, after_r = ctypes.c_uint64(), ctypes.c_uint64()
+    N.lib().picha_hip_async_stats(ctypes.byref(after_b), ctypes.byref(after_r))
+    assert after_r.value - before_r.value == len(jobs)
+    assert after_b.value - before_b.value <= len(jobs)  # coalescing can only reduce the number of launches
+    for (kind, img, opts), (err, out) in zip(jobs, results):
+        assert err is None
+        sync = (picha_amd.resizeSync if kind == "resize" else picha_amd.colorConvertSync)(img, opts)
+        assert sync.equalPixels(out), (kind, opts)
+
+
+def test_async_argument_errors_are_synchronous():
+    """like the reference, argument problems throw at the call, never reach the callback"""
+    img = rand_image(np.random.default_rng(1), 8, 8, "rgba")
+    called = []
+    with pytest.raises(picha_amd.PichaError) as e:
+        picha_amd.resize(img, {"width": 0, "height": 4}, lambda err, out: called.append(1))
+    assert str(e.value) == "invalid dimensions"
+    with pytest.raises(picha_amd.PichaError):
+        picha_amd.colorConvert(img, {"pixel": "nope"}, lambda err, out: called.append(1))
+    picha_amd.drain()
+    assert not called
