@@ -316,3 +316,25 @@ def test_async_argument_errors_are_synchronous():
         picha_amd.colorConvert(img, {"pixel": "nope"}, lambda err, out: called.append(1))
     picha_amd.drain()
     assert not called
+
+
+def test_resize_16bit_streaming_kernel_rotating_accumulators():
+    """r16g16b16a16 at integer scales runs the row-granular streaming variant (cfg5's kernel)."""
+    rng = np.random.default_rng(55)
+    cases = [((256, 96), (64, 24), {"filter": "mitchel"}),     # 4x, 15 taps: cfg5's structure
+             ((130, 68), (65, 34), {}),                          # 2x default cubic, 5 taps
+             ((130, 68), (65, 34), {"filter": "cubic"})]         # 2x, 7 taps
+    for (sw, sh), (dw, dh), opts in cases:
+        img = rand_image(rng, sw, sh, "r16g16b16a16")
+        for chunks in (0, 1, 2):
+            set_path(2)
+            set_opt("row_chunks", chunks)
+            got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
+            name = N.lib().picha_hip_last_kernel().decode()
+            assert name.startswith("resize_stream") and "rot" in name, name
+            exp = oracle_resize(img, dw, dh, opts.get("filter", "cubic"), 1.0 if "filter" in opts else 0.70)
+            assert max_code_diff(got, exp) == 0, (sw, sh, opts, chunks, name)
+        set_opt("numerics", 1)
+        got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
+        assert max_code_diff(got, exp) <= 1
+        set_opt("numerics", 0)
