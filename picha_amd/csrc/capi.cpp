@@ -64,6 +64,7 @@ long g_opt_numerics = [] {
     return (e && strcmp(e, "fma") == 0) ? 1L : 0L;
 }();
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
+long g_opt_stream_rot = 0;  // 0 auto, 1 force the rotating-accumulator streaming variant, 2 force the unrolled one
 
 // ---- per-device state ---------------------------------------------------------------------------
 struct DeviceAxis {
@@ -408,10 +409,11 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     rc = get_axis(ctx, filter, fscale, s0.height, d0.height, &ay);
     if (rc) return rc;
 
-    long opt_path, opt_chunks, opt_numerics, opt_per_lane;
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
+        opt_rot = g_opt_stream_rot;
     }
     const int fma = opt_numerics == 1 ? 1 : 0;
     const int is16 = pixel >= PICHA_R16;
@@ -452,7 +454,11 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         for (int pl : cand_s) {
             if (opt_per_lane > 0 && pl != opt_per_lane) continue;
             if (opt_per_lane == 0 && pl == 4) continue;
-            if (!stream_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps)) continue;
+            // unrolled-roles variant first (fastest where it exists), rotating variant otherwise
+            int rot = -1;
+            if (opt_rot != 1 && stream_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps, 0)) rot = 0;
+            else if (opt_rot != 2 && stream_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps, 1)) rot = 1;
+            if (rot < 0) continue;
             const DeviceAxis::XTable *cx = nullptr;
             const DeviceAxis::YStream *cy = nullptr;
             rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, fma, is16, &cx);
@@ -481,6 +487,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             p.x_per_lane = pl; p.x_step = sx; p.x_groups = cx->groups; p.xw_stride = cx->stride;
             p.fma = fma;
             p.y_step_weight = cy->step_weight; p.y_step = sy; p.y_taps = ay->host.taps; p.y_base = cy->base;
+            p.rot = rot;
             const long long col_waves = (cx->groups + 63) / 64;
             long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
             chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
@@ -850,6 +857,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "row_chunks") == 0) { g_opt_row_chunks = value; return PICHA_OK; }
     if (strcmp(key, "numerics") == 0) { g_opt_numerics = value; return PICHA_OK; }
     if (strcmp(key, "per_lane") == 0) { g_opt_per_lane = value; return PICHA_OK; }
+    if (strcmp(key, "stream_rot") == 0) { g_opt_stream_rot = value; return PICHA_OK; }
     return fail(PICHA_ERR_ARGUMENT, "unknown option %s", key);
 }
 long picha_hip_get_option(const char *key) {
@@ -859,6 +867,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "row_chunks") == 0) return g_opt_row_chunks;
     if (strcmp(key, "numerics") == 0) return g_opt_numerics;
     if (strcmp(key, "per_lane") == 0) return g_opt_per_lane;
+    if (strcmp(key, "stream_rot") == 0) return g_opt_stream_rot;
     return -1;
 }
 

@@ -99,9 +99,10 @@ struct StreamParams {
     // output row y reads source rows y_step*y + y_base + j, j < y_taps
     const float *y_step_weight;  // [dst_h + (y_taps-1)/y_step][YW]; YW = roundup4(ceil(y_taps/y_step)*y_step)
     int y_step, y_taps, y_base;
+    int rot;  // 1: row-granular variant with rotating accumulators; 0: step-granular, fully unrolled roles
     int rows_per_chunk, n_chunks;
 };
-bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty);
+bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot);
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 
 // ---- synthetic pixels ---------------------------------------------------------------------------

@@ -12,8 +12,8 @@ PICHA_DECL_SPAN(4) PICHA_DECL_SPAN(5) PICHA_DECL_SPAN(6) PICHA_DECL_SPAN(7)
 #undef PICHA_DECL_SPAN
 
 
-bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty) {
-    return stream_supported(pixel, per_lane, sx, tx, sy, ty);
+bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot) {
+    return stream_supported(pixel, per_lane, sx, tx, sy, ty, rot);
 }
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **name) {
     return launch_resize_stream(pixel, p, s, name);
