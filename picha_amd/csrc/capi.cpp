@@ -454,10 +454,16 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         for (int pl : cand_s) {
             if (opt_per_lane > 0 && pl != opt_per_lane) continue;
             if (opt_per_lane == 0 && pl == 4) continue;
-            // unrolled-roles variant first (fastest where it exists), rotating variant otherwise
+            // two variants of the streaming kernel; measured (interleaved A/B on cfg2, 5 and 7 taps): the
+            // unrolled-roles one is as fast or faster except for the reference arithmetic with > 5 taps,
+            // where the rotating one's lower register count wins
+            const bool prefer_rot = opt_rot == 1 || (opt_rot == 0 && !fma && ax->host.taps > 5);
             int rot = -1;
-            if (opt_rot != 1 && stream_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps, 0)) rot = 0;
-            else if (opt_rot != 2 && stream_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps, 1)) rot = 1;
+            for (int attempt = 0; attempt < 2 && rot < 0; ++attempt) {
+                const int r = (attempt == 0) == prefer_rot ? 1 : 0;
+                if ((opt_rot == 1 && r == 0) || (opt_rot == 2 && r == 1)) continue;
+                if (stream_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps, r)) rot = r;
+            }
             if (rot < 0) continue;
             const DeviceAxis::XTable *cx = nullptr;
             const DeviceAxis::YStream *cy = nullptr;

@@ -8,7 +8,8 @@ def opt(k, v): N.check(N.lib().picha_hip_set_option(k.encode(), v))
 torch.cuda.set_device(0)
 src = DeviceBatch(256, 3840, 2160, 'rgba').fill_random(1)
 dst = DeviceBatch(256, 1920, 1080, 'rgba')
-plan = ResizePlan(src, dst)
+plan_opts = json.loads(sys.argv[2]) if len(sys.argv) > 2 else {}
+plan = ResizePlan(src, dst, filter=plan_opts.get('filter'), filter_scale=plan_opts.get('filterScale'))
 variants = [dict(numerics=n, per_lane=p, path=pa) for n in (0, 1) for (p, pa) in ((2, 2), (1, 2), (4, 2), (2, 3))]
 if len(sys.argv) > 1:
     variants = json.loads(sys.argv[1])
