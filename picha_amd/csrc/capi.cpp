@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <climits>
 #include <cstring>
+#include <deque>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -90,6 +91,15 @@ struct DeviceAxis {
         int base = 0;                  // output y reads source rows step*y + base + j
     };
     std::map<std::pair<int, int>, YStream> ystreams;
+
+    DeviceAxis() = default;
+    DeviceAxis(const DeviceAxis &) = delete;
+    DeviceAxis &operator=(const DeviceAxis &) = delete;
+    ~DeviceAxis() {  // hipFree waits for the device, so kernels still reading these tables finish first
+        if (blob) (void)hipFree(blob);
+        for (auto &kv : xtables) if (kv.second.blob) (void)hipFree(kv.second.blob);
+        for (auto &kv : ystreams) if (kv.second.blob) (void)hipFree(kv.second.blob);
+    }
     // fused, y role
     int4 *y_info = nullptr;
     float *y_weight = nullptr;  // [dst][y_pad]
@@ -112,9 +122,12 @@ struct TempBuf {
     bool pending = false;
 };
 
+constexpr size_t kMaxCachedAxes = 256;  // distinct (filter, scale, src, dst) axes kept per device
+
 struct DeviceCtx {
     std::mutex mu;
-    std::map<AxisKey, std::unique_ptr<DeviceAxis>> axes;
+    std::map<AxisKey, std::shared_ptr<DeviceAxis>> axes;
+    std::deque<AxisKey> axis_order;  // insertion order, for eviction
     std::mutex temp_mu;  // held from temp_acquire to temp_release
     TempBuf scratch;     // two-pass float scratch
     TempBuf tables;      // per-image pointer tables
@@ -174,17 +187,17 @@ int temp_release(TempBuf &t, hipStream_t s) {
 
 // Builds (once) and uploads the tables for one axis.  Synchronous on first use of a geometry;
 // afterwards a pure lookup.
-int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, DeviceAxis **out) {
+int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, std::shared_ptr<DeviceAxis> *out) {
     uint32_t bits;
     memcpy(&bits, &fscale, 4);
     AxisKey key(filter, bits, src, dst);
     std::lock_guard<std::mutex> lk(ctx->mu);
     auto it = ctx->axes.find(key);
     if (it != ctx->axes.end()) {
-        *out = it->second.get();
+        *out = it->second;
         return PICHA_OK;
     }
-    std::unique_ptr<DeviceAxis> ax(new DeviceAxis);
+    std::shared_ptr<DeviceAxis> ax(new DeviceAxis);
     int rc = build_axis_taps(filter, fscale, src, dst, ax->host);
     if (rc != PICHA_OK) return fail(rc, "%s", picha_hip_strerror(rc));
     const AxisTaps &t = ax->host;
@@ -227,8 +240,15 @@ int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, DeviceA
         off += align_up(p.bytes, 256);
     }
     HIP_TRY(hipMemcpy(ax->blob, image.data(), total, hipMemcpyHostToDevice));
-    *out = ax.get();
-    ctx->axes[key] = std::move(ax);
+    *out = ax;
+    ctx->axes[key] = ax;
+    ctx->axis_order.push_back(key);
+    // bounded cache: a service that sees arbitrary geometries must not grow without limit.  Callers hold
+    // shared_ptrs while they enqueue work, so an evicted axis is freed only after its last user is done.
+    while (ctx->axis_order.size() > kMaxCachedAxes) {
+        ctx->axes.erase(ctx->axis_order.front());
+        ctx->axis_order.pop_front();
+    }
     return PICHA_OK;
 }
 
@@ -403,11 +423,12 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                  float fscale, hipStream_t s) {
     const picha_image &s0 = src[0], &d0 = dst[0];
     const int pixel = s0.pixel;
-    DeviceAxis *ax = nullptr, *ay = nullptr;
-    int rc = get_axis(ctx, filter, fscale, s0.width, d0.width, &ax);
+    std::shared_ptr<DeviceAxis> ax_ref, ay_ref;  // keep the tables alive while launches are enqueued
+    int rc = get_axis(ctx, filter, fscale, s0.width, d0.width, &ax_ref);
     if (rc) return rc;
-    rc = get_axis(ctx, filter, fscale, s0.height, d0.height, &ay);
+    rc = get_axis(ctx, filter, fscale, s0.height, d0.height, &ay_ref);
     if (rc) return rc;
+    DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
     long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot;
     {

@@ -338,3 +338,21 @@ def test_resize_16bit_streaming_kernel_rotating_accumulators():
         got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
         assert max_code_diff(got, exp) <= 1
         set_opt("numerics", 0)
+
+
+def test_tap_table_cache_is_bounded_and_eviction_is_safe():
+    """More distinct geometries than the per-device cache holds: results stay correct throughout."""
+    rng = np.random.default_rng(9)
+    img = rand_image(rng, 97, 53, "rgba")
+    first = picha_amd.resizeSync(img, {"width": 40, "height": 20})
+    for k in range(300):  # 300 distinct x axes + y axes > 256 cached axes
+        w, h = 10 + k % 60, 8 + k // 7
+        got = picha_amd.resizeSync(img, {"width": w, "height": h, "filter": FILTERS[k % 6]})
+        if k % 37 == 0:
+            try:
+                exp = oracle_resize(img, w, h, FILTERS[k % 6], 1.0)
+            except RuntimeError:
+                continue
+            assert max_code_diff(got, exp) == 0
+    again = picha_amd.resizeSync(img, {"width": 40, "height": 20})  # its tables were evicted and rebuilt
+    assert first.equalPixels(again)
