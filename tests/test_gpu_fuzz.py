@@ -1,0 +1,108 @@
+"""Randomised parity sweep: geometry, format, filter, filterScale, stride padding, subView offsets and
+kernel family drawn at random; every result must equal the oracle bit for bit (fma flavour: <= 1)."""
+import numpy as np
+import pytest
+
+import picha_amd
+from picha_amd import _native as N
+from util import FILTERS, PIXELS, max_code_diff, oracle_convert, oracle_resize, payload, rand_image
+
+pytestmark = pytest.mark.gpu
+
+
+def set_opt(key, v):
+    N.check(N.lib().picha_hip_set_option(key.encode(), v))
+
+
+@pytest.fixture(autouse=True)
+def _reset():
+    yield
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot"):
+        set_opt(k, 0)
+
+
+def _sizes(rng):
+    kind = rng.integers(0, 6)
+    if kind == 0:    # exact integer decimation (streaming kernels)
+        f = int(rng.choice([1, 2, 2, 2, 3, 4]))
+        dw, dh = int(rng.integers(1, 300)), int(rng.integers(1, 120))
+        return dw * f, dh * f, dw, dh
+    if kind == 1:    # tiny
+        return tuple(int(v) for v in rng.integers(1, 9, size=4))
+    if kind == 2:    # strong downscale
+        dw, dh = int(rng.integers(1, 40)), int(rng.integers(1, 30))
+        return dw * int(rng.integers(3, 12)) + int(rng.integers(0, 5)), dh * int(rng.integers(3, 9)) + int(rng.integers(0, 4)), dw, dh
+    if kind == 3:    # upscale
+        sw, sh = int(rng.integers(1, 60)), int(rng.integers(1, 40))
+        return sw, sh, sw * int(rng.integers(1, 5)) + int(rng.integers(0, 7)), sh * int(rng.integers(1, 4)) + int(rng.integers(0, 5))
+    if kind == 4:    # wide outputs: several workgroups, ragged last lane group
+        return int(rng.integers(600, 1500)), int(rng.integers(4, 40)), int(rng.integers(257, 700)), int(rng.integers(2, 30))
+    return int(rng.integers(1, 200)), int(rng.integers(1, 150)), int(rng.integers(1, 200)), int(rng.integers(1, 150))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_resizes_match_oracle(seed):
+    rng = np.random.default_rng(1000 + seed)
+    checked = 0
+    for _ in range(70):
+        sw, sh, dw, dh = _sizes(rng)
+        pixel = PIXELS[int(rng.integers(0, 8))]
+        img = rand_image(rng, sw + int(rng.integers(0, 4)), sh + int(rng.integers(0, 3)), pixel, pad=int(rng.choice([0, 0, 4, 8])),
+                         edge_values=bool(rng.integers(0, 4) == 0))
+        if img.width > sw or img.height > sh:  # exercise subViews (offset + parent stride; may be unaligned)
+            img = img.subView(img.width - sw, img.height - sh, sw, sh)
+        opts = {"width": dw, "height": dh}
+        filt, fscale = "cubic", 0.70
+        if rng.integers(0, 4) > 0:
+            filt = FILTERS[int(rng.integers(0, 6))]
+            opts["filter"] = filt
+            fscale = 1.0
+        if rng.integers(0, 3) == 0:
+            fscale = float(rng.choice([0.5, 0.7, 1.0, 1.5, 2.25]))
+            opts["filterScale"] = fscale
+        try:
+            exp = oracle_resize(img, dw, dh, filt, fscale)
+        except RuntimeError as e:
+            assert "rc=-7" in str(e)
+            with pytest.raises(picha_amd.PichaError):
+                picha_amd.resizeSync(img, opts)
+            continue
+        path = int(rng.choice([0, 0, 1, 3]))
+        numerics = int(rng.integers(0, 4) == 0)
+        set_opt("path", path)
+        set_opt("numerics", numerics)
+        set_opt("per_lane", int(rng.choice([0, 0, 1, 2, 4])))
+        set_opt("row_chunks", int(rng.choice([0, 0, 1, 2, 7])))
+        set_opt("stream_rot", int(rng.choice([0, 1, 2])))
+        try:
+            got = picha_amd.resizeSync(img, opts)
+        except picha_amd.PichaError as e:
+            if path != 3 or "unsupported" not in str(e):
+                raise
+            set_opt("path", 0)  # forcing a fused kernel is legitimately refused (tap count, alignment): use auto
+            path = 0
+            got = picha_amd.resizeSync(img, opts)
+        d = max_code_diff(got, exp)
+        name = N.lib().picha_hip_last_kernel().decode()
+        assert d <= (1 if numerics and path != 1 else 0), (seed, sw, sh, dw, dh, pixel, opts, path, numerics, name, d)
+        checked += 1
+    assert checked > 40
+
+
+def test_random_color_converts_match_oracle():
+    rng = np.random.default_rng(77)
+    for _ in range(200):
+        w, h = int(rng.integers(1, 300)), int(rng.integers(1, 40))
+        sp, dp = PIXELS[int(rng.integers(0, 8))], PIXELS[int(rng.integers(0, 8))]
+        img = rand_image(rng, w + int(rng.integers(0, 3)), h, sp, pad=int(rng.choice([0, 4])))
+        if img.width > w:
+            img = img.subView(img.width - w, 0, w, h)
+        opts = {"pixel": dp}
+        wts = None
+        if rng.integers(0, 3) == 0:
+            r, g, b = (float(v) for v in rng.uniform(0.05, 2.0, size=3))
+            opts.update(redWeight=r, greenWeight=g, blueWeight=b)
+            wts = picha_amd.color_settings(r, g, b)
+        got = picha_amd.colorConvertSync(img, opts)
+        exp = oracle_convert(img, dp, weights=wts)
+        assert np.array_equal(payload(got), payload(exp)), (w, h, sp, dp, opts)
