@@ -336,7 +336,7 @@ int get_ystream(DeviceCtx *ctx, DeviceAxis *ay, int step, int taps, const Device
     ys.base = base;
     if (ok) {
         const int npend = (taps - 1) / step + 1, iclose = (taps - 1) / step;
-        const int yw = (npend * step + 3) / 4 * 4;
+        const int yw = (npend * step + 1 + 3) / 4 * 4;  // weights + "same as previous record" flag in the last dword
         const int nsteps = dst + iclose;
         std::vector<float> tab((size_t)nsteps * yw, 0.0f);
         for (int y = 0; y < dst; ++y) {
@@ -346,6 +346,10 @@ int get_ystream(DeviceCtx *ctx, DeviceAxis *ay, int step, int taps, const Device
                 const int i = tap / step, ph = tap % step;
                 tab[(size_t)(y + i) * yw + i * step + ph] = t.weight[(size_t)y * T + j];
             }
+        }
+        for (int m = 1; m < nsteps; ++m) {
+            const int32_t same = memcmp(&tab[(size_t)m * yw], &tab[(size_t)(m - 1) * yw], sizeof(float) * npend * step) == 0;
+            memcpy(&tab[(size_t)m * yw + yw - 1], &same, 4);
         }
         HIP_TRY(hipMalloc(&ys.blob, tab.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(ys.blob, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -469,16 +473,18 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (fused_ok && opt_path != 1 && opt_path != 3) {
         const int sx = std::max(1, (int)std::lround((double)s0.width / d0.width));
         const int sy = std::max(1, (int)std::lround((double)s0.height / d0.height));
-        // measured on MI355X (interleaved A/B, cfg2): reference arithmetic is fastest with 2 outputs per
-        // lane (fewer conversions per output), the fma flavour with 1 (more waves in flight)
-        const int cand_s[] = {fma ? 1 : 2, fma ? 2 : 1, 4};
+        // measured on MI355X (interleaved A/B on cfg2, profiles/): all lane layouts land within ~4 %; one
+        // output per lane with the rotating-accumulator variant is the best or within noise of the best for
+        // both numerics, and has the smallest code and register footprint
+        // ... except the reference arithmetic with more than 5 taps, where two outputs per lane (fewer
+        // conversions per output) wins by ~9 %
+        const bool two_first = !fma && ax->host.taps > 5;
+        const int cand_s[] = {two_first ? 2 : 1, two_first ? 1 : 2, 4};
         for (int pl : cand_s) {
             if (opt_per_lane > 0 && pl != opt_per_lane) continue;
             if (opt_per_lane == 0 && pl == 4) continue;
-            // two variants of the streaming kernel; measured (interleaved A/B on cfg2, 5 and 7 taps): the
-            // unrolled-roles one is as fast or faster except for the reference arithmetic with > 5 taps,
-            // where the rotating one's lower register count wins
-            const bool prefer_rot = opt_rot == 1 || (opt_rot == 0 && !fma && ax->host.taps > 5);
+            // two variants of the streaming kernel: rotating accumulators (default) or unrolled roles
+            const bool prefer_rot = opt_rot != 2;
             int rot = -1;
             for (int attempt = 0; attempt < 2 && rot < 0; ++attempt) {
                 const int r = (attempt == 0) == prefer_rot ? 1 : 0;

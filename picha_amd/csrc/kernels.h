@@ -97,7 +97,8 @@ struct StreamParams {
     int x_taps, x_per_lane, x_step, x_groups, xw_stride;
     int fma;
     // output row y reads source rows y_step*y + y_base + j, j < y_taps
-    const float *y_step_weight;  // [dst_h + (y_taps-1)/y_step][YW]; YW = roundup4(ceil(y_taps/y_step)*y_step)
+    const float *y_step_weight;  // [dst_h + (y_taps-1)/y_step][YW]; YW = roundup4(ceil(y_taps/y_step)*y_step + 1);
+                                 // last dword of a record: int flag, 1 = weights identical to the previous record
     int y_step, y_taps, y_base;
     int rot;  // 1: row-granular variant with rotating accumulators; 0: step-granular, fully unrolled roles
     int rows_per_chunk, n_chunks;
