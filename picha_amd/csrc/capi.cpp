@@ -276,12 +276,17 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
     // byte-span kernels read whole dwords from the window start: the window (taps*bpp bytes, a
     // multiple of 4) must end inside the row, so windows near the right edge are shifted left and
     // their weights move to the back (zero weights in front leave the sum unchanged)
-    const int max_left = bytespan_bpp ? t.src_size - taps : INT32_MAX;
+    // ... and they start on a 4-byte boundary of the row (byte-unaligned dwordx4 loads run at a fraction of
+    // the aligned rate): the window start is rounded down to `align_px` pixels, the weights move back by as much
+    const int align_px = bytespan_bpp ? ((bytespan_bpp % 2) ? 4 : 2) : 1;
+    int max_left = bytespan_bpp ? t.src_size - taps : INT32_MAX;
+    if (bytespan_bpp) max_left -= ((max_left % align_px) + align_px) % align_px;
     if (bytespan_bpp && max_left < 0) ok = false;
     for (int g = 0; g < groups && ok; ++g) {
         int base = INT32_MAX;
         for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) base = std::min(base, t.left[g * per_lane + q] - step * q);
         base = std::min(base, max_left);
+        if (bytespan_bpp) base -= base % align_px;
         left[g] = base;
         for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) {
             const int i = g * per_lane + q;
@@ -452,7 +457,9 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) fused_ok = false;
         if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % al) fused_ok = false;
     }
-    int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps, pixel);
+    // sub-dword pixels fetched as dwords get their window aligned down (up to 3 pixels): leave room for it
+    const int align_room = (kBytes[pixel] % 4 == 0 || ax->host.taps <= 3) ? 0 : ((kBytes[pixel] % 2) ? 3 : 1);
+    int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps + align_room, pixel);
     const DeviceAxis::XTable *xt = nullptr;
     if (fused_ok && opt_per_lane != 1) {
         // integer decimation / interpolation step of the tap windows

@@ -54,7 +54,7 @@ hipError_t launch_resize_twopass(int pixel, const TwoPassParams &p, hipStream_t 
 int fused_y_pad(int y_taps) { return y_taps <= 8 ? 8 : (y_taps <= 16 ? 16 : 32); }
 
 int fused_x_bucket(int x_taps, int pixel) {
-    static const int buckets[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32};
+    static const int buckets[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 36};
     const int bpp = pixel_channels(pixel) * (pixel_is16(pixel) ? 2 : 1);
     for (int b : buckets) {
         if (x_taps > b) continue;
