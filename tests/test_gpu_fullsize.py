@@ -130,3 +130,33 @@ def test_non_uniform_pitch_batches_use_pointer_tables():
     for i in range(5):
         exp = oracle_resize(a.image_host(i), 320, 240, "cubic", 0.70)
         assert np.array_equal(out.image_host(i).pixels(), exp.pixels())
+
+
+def test_device_entry_point_is_graph_capturable():
+    """With the tap tables cached the device entry point neither allocates nor synchronises, so a batch
+    resize can be captured into a HIP graph (torch.cuda.CUDAGraph on the capture stream) and replayed."""
+    src = DeviceBatch(16, 1280, 720, "rgba").fill_random(21)
+    dst = DeviceBatch(16, 640, 360, "rgba")
+    from picha_amd.device import ResizePlan
+    plan = ResizePlan(src, dst)
+    plan.run()  # warm: builds and uploads the tables (allocation + upload happen here, outside the capture)
+    torch.cuda.synchronize()
+    want = digest(dst)
+    dst.tensor.zero_()
+    g = torch.cuda.CUDAGraph()
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        with torch.cuda.graph(g, stream=s):
+            plan.run(stream=s.cuda_stream)
+    torch.cuda.synchronize()
+    assert digest(dst) != want  # capture only records
+    g.replay()
+    torch.cuda.synchronize()
+    assert digest(dst) == want
+    src.fill_random(22)   # new pixels, same graph
+    torch.cuda.synchronize()
+    g.replay()
+    torch.cuda.synchronize()
+    exp = oracle_resize(src.image_host(3), 640, 360, "cubic", 0.70)
+    assert np.array_equal(dst.image_host(3).pixels(), exp.pixels())
