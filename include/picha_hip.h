@@ -125,6 +125,7 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "per_lane"   0 = auto, else output columns per lane for the fused kernels (1, 2, 4)
  *   "row_chunks" 0 = auto, else number of row chunks per image for the fused kernels
  *   "stream_rot" 0 = auto, 1 / 2 = force the rotating-accumulator / unrolled variant of the streaming kernel
+ *   "dpp"        1 = use the cross-lane pixel-sharing streaming kernel where it applies (rgba, 2x, 5 taps)
  * Returns PICHA_ERR_ARGUMENT for an unknown key.
  */
 int picha_hip_set_option(const char *key, long value);

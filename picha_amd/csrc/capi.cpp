@@ -66,6 +66,7 @@ long g_opt_numerics = [] {
 }();
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 long g_opt_stream_rot = 0;  // 0 auto, 1 force the rotating-accumulator streaming variant, 2 force the unrolled one
+long g_opt_dpp = 0;         // 0 auto, 1 prefer / 2 forbid the cross-lane pixel-sharing streaming kernel
 
 // ---- per-device state ---------------------------------------------------------------------------
 struct DeviceAxis {
@@ -81,6 +82,7 @@ struct DeviceAxis {
         int32_t *left = nullptr;  // [groups]
         float *weight = nullptr;  // [taps][stride]
         int groups = 0, stride = 0;
+        int l0 = 0;  // uniform_base tables: the common window offset (window of output x starts at step*x + l0)
     };
     std::map<std::tuple<int, int, int, int, int>, XTable> xtables;
     // streaming kernel, y role: uniform-stride view of the table, built on demand per (step, taps)
@@ -259,9 +261,9 @@ int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, std::sh
 // pixels a padded tap addresses are either inside the image (finite, times 0) or outside it (the
 // kernel's buffer loads return 0).  fma: weights pre-multiplied by 1/max of the sample type.
 int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps, int fma, int is16,
-               const DeviceAxis::XTable **out, int bytespan_bpp = 0) {
+               const DeviceAxis::XTable **out, int bytespan_bpp = 0, bool uniform_base = false) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    auto key = std::make_tuple(per_lane, step, taps, fma, is16 + 16 * bytespan_bpp);
+    auto key = std::make_tuple(per_lane, step, taps, fma, is16 + 16 * bytespan_bpp + (uniform_base ? 4096 : 0));
     auto it = ax->xtables.find(key);
     if (it != ax->xtables.end()) { *out = &it->second; return PICHA_OK; }
     DeviceAxis::XTable xt;
@@ -282,12 +284,18 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
     int max_left = bytespan_bpp ? t.src_size - taps : INT32_MAX;
     if (bytespan_bpp) max_left -= ((max_left % align_px) + align_px) % align_px;
     if (bytespan_bpp && max_left < 0) ok = false;
+    // uniform_base: every window starts at step*x + L0 with one L0 for the whole axis (the cross-lane
+    // sharing kernel addresses neighbours' pixels by lane distance); left[] then holds L0 in every entry
+    int l0 = INT32_MAX;
+    if (uniform_base)
+        for (int i = 0; i < dst; ++i) l0 = std::min(l0, t.left[i] - step * i);
     for (int g = 0; g < groups && ok; ++g) {
         int base = INT32_MAX;
         for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) base = std::min(base, t.left[g * per_lane + q] - step * q);
+        if (uniform_base) base = step * g * per_lane + l0;
         base = std::min(base, max_left);
         if (bytespan_bpp) base -= base % align_px;
-        left[g] = base;
+        left[g] = uniform_base ? l0 : base;
         for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) {
             const int i = g * per_lane + q;
             const int first = t.left[i] - (base + step * q);  // >= 0 by construction
@@ -299,6 +307,7 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
         }
     }
     xt.ok = ok;
+    xt.l0 = uniform_base ? l0 : 0;
     if (ok) {
         const size_t lb = align_up(sizeof(int32_t) * groups, 256), wb = sizeof(float) * weight.size();
         std::vector<uint8_t> image(lb + wb, 0);
@@ -439,11 +448,12 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (rc) return rc;
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
-    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot;
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
         opt_rot = g_opt_stream_rot;
+        opt_dpp = g_opt_dpp;
     }
     const int fma = opt_numerics == 1 ? 1 : 0;
     const int is16 = pixel >= PICHA_R16;
@@ -487,12 +497,19 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         // conversions per output) wins by ~9 %
         const bool two_first = !fma && ax->host.taps > 5;
         const int cand_s[] = {two_first ? 2 : 1, two_first ? 1 : 2, 4};
+        // cross-lane sharing variant (rgba8, exact 2x, 5 taps): fewest conversions per output and fully
+        // coalesced loads, but measured 2-4 % SLOWER than the plain variant on cfg2 (the kernel is bound by
+        // mixed read/write HBM traffic, not by the conversions it saves): opt-in only ("dpp" = 1)
+        bool want_dpp = opt_dpp == 1 && stream_dpp_supported(pixel, sx, ax->host.taps, sy, ay->host.taps);
         for (int pl : cand_s) {
-            if (opt_per_lane > 0 && pl != opt_per_lane) continue;
-            if (opt_per_lane == 0 && pl == 4) continue;
+            if (want_dpp && pl != 1) continue;
+            if (!want_dpp) {
+                if (opt_per_lane > 0 && pl != opt_per_lane) continue;
+                if (opt_per_lane == 0 && pl == 4) continue;
+            }
             // two variants of the streaming kernel: rotating accumulators (default) or unrolled roles
             const bool prefer_rot = opt_rot != 2;
-            int rot = -1;
+            int rot = want_dpp ? 1 : -1;
             for (int attempt = 0; attempt < 2 && rot < 0; ++attempt) {
                 const int r = (attempt == 0) == prefer_rot ? 1 : 0;
                 if ((opt_rot == 1 && r == 0) || (opt_rot == 2 && r == 1)) continue;
@@ -501,10 +518,19 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             if (rot < 0) continue;
             const DeviceAxis::XTable *cx = nullptr;
             const DeviceAxis::YStream *cy = nullptr;
-            rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, fma, is16, &cx);
+            rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, fma, is16, &cx, 0, want_dpp);
             if (rc) return rc;
             rc = get_ystream(ctx, ay, sy, ay->host.taps, &cy);
             if (rc) return rc;
+            if (want_dpp && (!cx->ok || !cy->ok || cx->l0 != -1)) {  // needs windows 2x-1 .. 2x+3
+                want_dpp = false;
+                rot = -1;
+                rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, fma, is16, &cx);
+                if (rc) return rc;
+                for (int r = 1; r >= 0 && rot < 0; --r)
+                    if (stream_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps, r)) rot = r;
+                if (rot < 0) continue;
+            }
             if (!cx->ok || !cy->ok) continue;
             StreamParams p{};
             long long sp = 0, dp = 0;
@@ -528,6 +554,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             p.fma = fma;
             p.y_step_weight = cy->step_weight; p.y_step = sy; p.y_taps = ay->host.taps; p.y_base = cy->base;
             p.rot = rot;
+            p.dpp = want_dpp ? 1 : 0;
             const long long col_waves = (cx->groups + 63) / 64;
             long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
             chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
@@ -898,6 +925,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "numerics") == 0) { g_opt_numerics = value; return PICHA_OK; }
     if (strcmp(key, "per_lane") == 0) { g_opt_per_lane = value; return PICHA_OK; }
     if (strcmp(key, "stream_rot") == 0) { g_opt_stream_rot = value; return PICHA_OK; }
+    if (strcmp(key, "dpp") == 0) { g_opt_dpp = value; return PICHA_OK; }
     return fail(PICHA_ERR_ARGUMENT, "unknown option %s", key);
 }
 long picha_hip_get_option(const char *key) {
@@ -908,6 +936,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "numerics") == 0) return g_opt_numerics;
     if (strcmp(key, "per_lane") == 0) return g_opt_per_lane;
     if (strcmp(key, "stream_rot") == 0) return g_opt_stream_rot;
+    if (strcmp(key, "dpp") == 0) return g_opt_dpp;
     return -1;
 }
 

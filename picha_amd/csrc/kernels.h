@@ -101,10 +101,12 @@ struct StreamParams {
                                  // last dword of a record: int flag, 1 = weights identical to the previous record
     int y_step, y_taps, y_base;
     int rot;  // 1: row-granular variant with rotating accumulators; 0: step-granular, fully unrolled roles
+    int dpp;  // 1: cross-lane pixel-sharing variant (x tables: per_lane 1, uniform base step*x + L0, L0 == -1)
     int rows_per_chunk, n_chunks;
 };
 bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot);
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
+bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty);
 
 // ---- synthetic pixels ---------------------------------------------------------------------------
 hipError_t launch_fill_random(void *dev, size_t bytes, uint64_t seed, int sample_bytes, hipStream_t s);

@@ -16,7 +16,11 @@ bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, in
     return stream_supported(pixel, per_lane, sx, tx, sy, ty, rot);
 }
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **name) {
+    if (p.dpp) return pixel == 1 ? launch_stream_dpp(p, s, name) : hipErrorInvalidValue;
     return launch_resize_stream(pixel, p, s, name);
+}
+bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty) {
+    return pixel == 1 && sx == 2 && tx == 5 && sy == 2 && ty == 5;
 }
 
 

@@ -31,6 +31,8 @@ def _reset_path():
     set_opt("numerics", 0)
     set_opt("per_lane", 0)
     set_opt("row_chunks", 0)
+    set_opt("stream_rot", 0)
+    set_opt("dpp", 0)
 
 
 def test_device_is_gfx950():
@@ -356,3 +358,25 @@ def test_tap_table_cache_is_bounded_and_eviction_is_safe():
             assert max_code_diff(got, exp) == 0
     again = picha_amd.resizeSync(img, {"width": 40, "height": 20})  # its tables were evicted and rebuilt
     assert first.equalPixels(again)
+
+
+def test_resize_rgba_2x_cross_lane_sharing_kernel():
+    """The DPP pixel-sharing streaming kernel (rgba8, exact 2x, 5 taps): bit-exact, including image edges,
+    widths that are not a multiple of the 62 outputs a wave produces, and row chunking."""
+    rng = np.random.default_rng(2026)
+    for (sw, sh) in [(640, 480), (124, 20), (126, 10), (2, 2), (130, 98), (1030, 36), (3840, 64)]:
+        img = rand_image(rng, sw, sh, "rgba", edge_values=(sw == 130))
+        exp = oracle_resize(img, sw // 2, sh // 2, "cubic", 0.70)
+        for chunks in (0, 1, 3):
+            set_path(2)
+            set_opt("dpp", 1)
+            set_opt("row_chunks", chunks)
+            got = picha_amd.resizeSync(img, {"width": sw // 2, "height": sh // 2})
+            name = N.lib().picha_hip_last_kernel().decode()
+            assert name.startswith("resize_stream_dpp") or sw < 16, name  # tiny images have fewer than 5 taps
+            assert max_code_diff(got, exp) == 0, (sw, sh, chunks, name)
+        set_opt("numerics", 1)
+        got = picha_amd.resizeSync(img, {"width": sw // 2, "height": sh // 2})
+        assert ("dpp" in N.lib().picha_hip_last_kernel().decode() or sw < 16) and max_code_diff(got, exp) <= 1
+        set_opt("numerics", 0)
+    set_opt("dpp", 0)
