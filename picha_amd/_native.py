@@ -8,7 +8,8 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-SO_PATH = os.path.join(HERE, "libpicha_hip.so")
+# PICHA_HIP_LIB: load another build of the same library (A/B measurements of two builds in one session)
+SO_PATH = os.environ.get("PICHA_HIP_LIB") or os.path.join(HERE, "libpicha_hip.so")
 
 PIXELS = ["rgb", "rgba", "grey", "greya", "r16", "r16g16", "r16g16b16", "r16g16b16a16"]
 FILTERS = ["cubic", "lanczos", "catmulrom", "mitchel", "box", "triangle"]

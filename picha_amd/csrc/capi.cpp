@@ -259,7 +259,8 @@ int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, std::sh
 // per_lane > 1 this needs the reference's tap table to have that uniform stride (true for integer
 // scale factors); the check below decides, the result is cached.  Taps are zero padded to `taps`;
 // pixels a padded tap addresses are either inside the image (finite, times 0) or outside it (the
-// kernel's buffer loads return 0).  fma: weights pre-multiplied by 1/max of the sample type.
+// kernel's buffer loads return 0).  fma = 1: weights pre-multiplied by 1/max of the sample type; fma = 2: the
+// reference's weights times 2^22 for kernels that unpack samples as scaled denormals (kernels_impl.inc, Sample::kDen).
 int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps, int fma, int is16,
                const DeviceAxis::XTable **out, int bytespan_bpp = 0, bool uniform_base = false) {
     std::lock_guard<std::mutex> lk(ctx->mu);
@@ -302,7 +303,7 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
             if (first + t.count[i] > taps) { ok = false; break; }
             for (int j = 0; j < t.count[i]; ++j) {
                 const float w = t.weight[(size_t)i * T + j];
-                weight[(size_t)(first + j) * stride + i] = fma ? w * inv : w;
+                weight[(size_t)(first + j) * stride + i] = fma == 1 ? w * inv : fma == 2 ? w * 4194304.0f : w;
             }
         }
     }
@@ -457,6 +458,8 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     }
     const int fma = opt_numerics == 1 ? 1 : 0;
     const int is16 = pixel >= PICHA_R16;
+    // x-weight flavour of the span/stream kernels: 1/max folded (fma), scaled by 2^22 (denormal unpack), or plain
+    const int xw_mode = fma ? 1 : exact_unpack_scaled(kChannels[pixel], is16 != 0) ? 2 : 0;
 
     // ---- pick the fused configuration: multi-output lanes where the table is uniform, else 1 per lane
     const int ring = std::max(ay->host.span, 1);
@@ -481,7 +484,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             if (!fused_multi_supported(pixel, pl, st, ax->host.taps)) continue;
             if (!fused_supported(pixel, ax->host.taps, ay->host.taps, ring, pl)) continue;
             const DeviceAxis::XTable *cx = nullptr;
-            rc = get_xtable(ctx, ax, pl, st, ax->host.taps, fma, is16, &cx);
+            rc = get_xtable(ctx, ax, pl, st, ax->host.taps, xw_mode, is16, &cx);
             if (rc) return rc;
             if (cx->ok) { xt = cx; per_lane = pl; step = st; ktaps = ax->host.taps; break; }
         }
@@ -518,14 +521,14 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             if (rot < 0) continue;
             const DeviceAxis::XTable *cx = nullptr;
             const DeviceAxis::YStream *cy = nullptr;
-            rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, fma, is16, &cx, 0, want_dpp);
+            rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, want_dpp ? fma : (xw_mode), is16, &cx, 0, want_dpp);
             if (rc) return rc;
             rc = get_ystream(ctx, ay, sy, ay->host.taps, &cy);
             if (rc) return rc;
             if (want_dpp && (!cx->ok || !cy->ok || cx->l0 != -1)) {  // needs windows 2x-1 .. 2x+3
                 want_dpp = false;
                 rot = -1;
-                rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, fma, is16, &cx);
+                rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, xw_mode, is16, &cx);
                 if (rc) return rc;
                 for (int r = 1; r >= 0 && rot < 0; --r)
                     if (stream_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps, r)) rot = r;
@@ -577,7 +580,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (fused_ok && !xt) {
         fused_ok = ktaps > 0 && fused_supported(pixel, ktaps, ay->host.taps, ring, 1);
         if (fused_ok) {
-            rc = get_xtable(ctx, ax, 1, 1, ktaps, fma, is16, &xt, fused_x_bytespan(ktaps, pixel) ? kBytes[pixel] : 0);
+            rc = get_xtable(ctx, ax, 1, 1, ktaps, xw_mode, is16, &xt, fused_x_bytespan(ktaps, pixel) ? kBytes[pixel] : 0);
             if (rc) return rc;
             fused_ok = xt->ok;
         }

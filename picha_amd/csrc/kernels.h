@@ -78,6 +78,12 @@ int fused_x_bucket(int x_taps, int pixel);
 // True if the kernel for that bucket fetches a sub-dword-pixel span as whole dwords: the host must then
 // keep every lane's window inside its row (shifted, zero-padded in front).
 bool fused_x_bytespan(int x_taps_bucket, int pixel);
+
+// Which formats the span/stream kernels unpack through the denormal form in the reference flavour (then the x weights
+// must be scaled by 2^22).  Measured r01 (profiles/r01_ab_denorm_unpack.txt): 16-bit samples −5.5 % kernel time (one
+// v_mul_f32_sdwa instead of and/shift + cvt + mul), grey −3 %; 8-bit multi-channel formats are 4–10 % SLOWER that
+// way (their v_cvt_f32_ubyteN overlaps with the multiply/add stream, an SDWA multiply does not), so they keep cvt + mul.
+constexpr bool exact_unpack_scaled(int channels, bool is16) { return is16 || channels == 1; }
 int fused_y_pad(int y_taps);
 hipError_t launch_resize_fused(int pixel, const FusedParams &p, hipStream_t s, const char **kernel_name);
 

@@ -7,7 +7,9 @@ out=$root/gpurun_out/prof_$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp
 args="--steps 3 --warmup 1 --no-cpu-baseline $@"
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py $args > $out/trace.log 2>&1 || exit 1
+# the trace pass runs the bench's default step counts so that its average kernel duration is comparable with the bench line
+rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 $root/bench.py --steps 20 --warmup 3 --no-cpu-baseline $@ > $out/trace.log 2>&1 || exit 1
+[ -n "$PROF_TRACE_ONLY" ] && { cd $root && python3 scripts/prof_summary.py $out > $out/summary.txt 2>&1; cat $out/summary.txt; exit 0; }
 i=0
 for set in \
   "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM" \
