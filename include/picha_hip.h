@@ -186,6 +186,43 @@ int picha_hip_resize_device(int n, const picha_image *src, const picha_image *ds
 int picha_hip_color_convert_device(int n, const picha_image *src, const picha_image *dst,
                                    float r_factor, float g_factor, float b_factor, void *stream);
 
+/* ---- next to the path: colorConvert and resize chained on the device -----------
+ * What a picha user writes as  resize(colorConvert(image, {pixel}), {width, height})  — or the other way
+ * round — as ONE call: both kernels run back to back on the device, the intermediate image never crosses
+ * PCIe and is produced in slices sized for the 256 MB Infinity Cache.  Results are bit-identical to the two
+ * reference calls in that order (the intermediate is quantised to the destination sample type in between,
+ * exactly as the reference's intermediate Buffer is).  src and dst may differ in pixel format AND size:
+ *   PICHA_CONVERT_THEN_RESIZE  colorConvert src to dst->pixel at the source size (src/colorconvert.cc:171-188),
+ *                              then resize (src/resize.cc:270-280)
+ *   PICHA_RESIZE_THEN_CONVERT  resize in src->pixel, then colorConvert to dst->pixel
+ * Same error behaviour as the two single operations.
+ */
+typedef enum picha_chain_order { PICHA_CONVERT_THEN_RESIZE = 0, PICHA_RESIZE_THEN_CONVERT = 1 } picha_chain_order;
+int picha_hip_convert_resize_device(int n, const picha_image *src, const picha_image *dst, int order,
+                                    float r_factor, float g_factor, float b_factor, int filter,
+                                    float filter_scale, void *stream);
+int picha_hip_convert_resize(const picha_image *src, const picha_image *dst, int order, float r_factor,
+                             float g_factor, float b_factor, int filter, float filter_scale);
+int picha_hip_convert_resize_batch(int n, const picha_image *src, const picha_image *dst, int order,
+                                   float r_factor, float g_factor, float b_factor, int filter,
+                                   float filter_scale);
+
+/* ---- next to the path: Image helpers on device-resident images ----------------
+ * Image.prototype.equalPixels / avgChannelDiff / copy (lib/image.js:57-96) without a D2H copy of the pixels.
+ * subView needs no call: it is {data + y*stride + x*bytes, same stride, w, h} (lib/image.js:76-87).
+ *
+ * compare: for each pair, the sum over the payload BYTES (not samples: lib/image.js:68-73 walks row(y)[x])
+ * of |a - b| and the number of differing bytes, written to the HOST arrays (either may be NULL); the call
+ * synchronises `stream`.  avgChannelDiff = sum / (height * width * bytes); equalPixels = differing == 0.
+ * Pairs whose width, height or pixel differ are not compared: sum and count are set to UINT64_MAX
+ * (the reference returns 255 / false for them).
+ * copy: payload bytes of the common top-left min(width) x min(height) rectangle; PICHA_ERR_PIXEL_MISMATCH if
+ * the formats differ ("can't copy pixels between different pixel types", lib/image.js:90-91).  Asynchronous.
+ */
+int picha_hip_image_compare_device(int n, const picha_image *a, const picha_image *b, uint64_t *sum_abs_diff,
+                                   uint64_t *differing_bytes, void *stream);
+int picha_hip_image_copy_device(int n, const picha_image *src, const picha_image *dst, void *stream);
+
 /* ---- device memory helpers for hosts without an allocator of their own (Node addon, C tests) --- */
 int picha_hip_malloc(void **dev_ptr, size_t bytes);
 int picha_hip_free(void *dev_ptr);

@@ -68,6 +68,11 @@ SYMBOLS = [
     ("picha_hip_async_stats", None, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     ("picha_hip_resize_device", _i, [_i, _P, _P, _i, _f, _vp]),
     ("picha_hip_color_convert_device", _i, [_i, _P, _P, _f, _f, _f, _vp]),
+    ("picha_hip_convert_resize_device", _i, [_i, _P, _P, _i, _f, _f, _f, _i, _f, _vp]),
+    ("picha_hip_convert_resize", _i, [_P, _P, _i, _f, _f, _f, _i, _f]),
+    ("picha_hip_convert_resize_batch", _i, [_i, _P, _P, _i, _f, _f, _f, _i, _f]),
+    ("picha_hip_image_compare_device", _i, [_i, _P, _P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), _vp]),
+    ("picha_hip_image_copy_device", _i, [_i, _P, _P, _vp]),
     ("picha_hip_malloc", _i, [ctypes.POINTER(_vp), _sz]),
     ("picha_hip_free", _i, [_vp]),
     ("picha_hip_memcpy_h2d", _i, [_vp, _vp, _sz, _vp]),
@@ -82,6 +87,32 @@ DONE_FN = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_int, ctypes.c_char_p)
 _lib = None
 
 
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.
+
+    PyTorch wheels carry their own libamdhip64 / libhsa-runtime64 and load them by path; a process that has already
+    loaded the system runtime (through libpicha_hip.so) and then imports torch ends up with two runtimes and torch
+    sees no GPU.  torch is only plumbing here (device-resident batches, bench), but when it is installed we let ITS
+    runtime be the one: load it first, without importing torch; libpicha_hip.so then binds to the same copy.
+    """
+    import importlib.util
+    import sys
+    if "torch" in sys.modules or os.environ.get("PICHA_HIP_SYSTEM_RUNTIME") == "1":
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libpicha_hip.so (once).  Raises ImportError if it has not been built."""
     global _lib
@@ -91,6 +122,7 @@ def lib():
                 "picha_amd: %s is missing — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C picha_amd/csrc`. There is no fallback implementation." % SO_PATH
             )
+        _preload_torch_hip_runtime()
         L = ctypes.CDLL(SO_PATH)
         for name, res, args in SYMBOLS:
             fn = getattr(L, name)  # AttributeError if the ABI lost a symbol

@@ -220,6 +220,28 @@ def colorConvert(image, opts, cb):
                                                                done, None), src, dst, cb)
 
 
+# ---- next to the path: both operations in one device round trip ---------------
+def convertResizeSync(image, opts):
+    """resizeSync(colorConvertSync(image, opts), opts) — or, with opts.order == 'resizeFirst',
+    colorConvertSync(resizeSync(image, opts), opts) — as one call: the intermediate image stays in HBM.
+
+    opts carries both option sets: pixel (+ redWeight/greenWeight/blueWeight) and width, height (+ filter,
+    filterScale).  Results are bit-identical to the two reference calls in that order; errors are theirs.
+    """
+    expected = "expected: convertResizeSync(image, opts)"
+    src, mid, cs = _prepare_convert(image, opts, expected)
+    width = _to_int32(_uint32(_get(opts, "width")))
+    height = _to_int32(_uint32(_get(opts, "height")))
+    if width <= 0 or height <= 0:
+        raise PichaError("invalid dimensions")
+    ftag, fscale = _resize_options(opts)
+    order = 1 if _get(opts, "order") == "resizeFirst" else 0
+    dst = _new_image(width, height, mid.pixel)
+    cdst = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index(dst.pixel))
+    N.check(N.lib().picha_hip_convert_resize(ctypes.byref(src[0]), ctypes.byref(cdst), order, cs[0], cs[1], cs[2], ftag, fscale))
+    return dst
+
+
 # ---- helpers exposed for tests / tools ----------------------------------------------------------
 def make_contribs(filter, filter_scale, src_size, dst_size):
     """The product's host tap builder (picha_amd/csrc/taps.cpp) -> (left, right, weights[dst, T])."""

@@ -64,6 +64,7 @@ long g_opt_numerics = [] {
     const char *e = getenv("PICHA_HIP_NUMERICS");
     return (e && strcmp(e, "fma") == 0) ? 1L : 0L;
 }();
+long g_opt_chain_window_mb = 96;  // intermediate bytes produced per slice of a chained convert+resize (fits the 256 MB MALL)
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 long g_opt_stream_rot = 0;  // 0 auto, 1 force the rotating-accumulator streaming variant, 2 force the unrolled one
 long g_opt_dpp = 0;         // 0 auto, 1 prefer / 2 forbid the cross-lane pixel-sharing streaming kernel
@@ -133,6 +134,10 @@ struct DeviceCtx {
     std::mutex temp_mu;  // held from temp_acquire to temp_release
     TempBuf scratch;     // two-pass float scratch
     TempBuf tables;      // per-image pointer tables
+    std::mutex chain_mu; // held while a chained convert+resize uses `chain`
+    TempBuf chain;       // intermediate images of picha_hip_convert_resize_device
+    std::mutex results_mu;
+    TempBuf results;     // picha_hip_image_compare_device: per-image sums (device + pinned mirror)
 };
 
 std::mutex g_ctx_mu;
@@ -746,11 +751,11 @@ int device_arena(int dev, size_t bytes, uint8_t **out) {
     return PICHA_OK;
 }
 
-enum class Op { Resize, Convert };
+enum class Op { Resize, Convert, Chain };
 
 // Shared host-pointer driver: stage in, run the device entry point, stage out payload rows.
 int run_host(Op op, int n, const picha_image *src, const picha_image *dst, int filter, float fscale,
-             float r, float g, float b) {
+             float r, float g, float b, int order = 0) {
     if (n < 0 || (n > 0 && (!src || !dst))) return fail(PICHA_ERR_ARGUMENT, "bad batch arguments");
     if (n == 0) return PICHA_OK;
     for (int i = 0; i < n; ++i) {
@@ -789,8 +794,9 @@ int run_host(Op op, int n, const picha_image *src, const picha_image *dst, int f
     hipError_t e0 = hipMemcpyAsync(arena, pinned, dst_begin, hipMemcpyHostToDevice, s);
     if (e0 != hipSuccess) rc = fail(PICHA_ERR_HIP, "H2D failed: %s", hipGetErrorString(e0));
     if (rc == PICHA_OK)
-        rc = (op == Op::Resize) ? picha_hip_resize_device(n, dsrc.data(), ddst.data(), filter, fscale, s)
-                                : picha_hip_color_convert_device(n, dsrc.data(), ddst.data(), r, g, b, s);
+        rc = (op == Op::Resize)    ? picha_hip_resize_device(n, dsrc.data(), ddst.data(), filter, fscale, s)
+             : (op == Op::Convert) ? picha_hip_color_convert_device(n, dsrc.data(), ddst.data(), r, g, b, s)
+                                   : picha_hip_convert_resize_device(n, dsrc.data(), ddst.data(), order, r, g, b, filter, fscale, s);
     if (rc == PICHA_OK) {
         hipError_t e = hipMemcpyAsync(pinned + dst_begin, arena + dst_begin, total - dst_begin, hipMemcpyDeviceToHost, s);
         if (e != hipSuccess) rc = fail(PICHA_ERR_HIP, "D2H failed: %s", hipGetErrorString(e));
@@ -929,6 +935,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "per_lane") == 0) { g_opt_per_lane = value; return PICHA_OK; }
     if (strcmp(key, "stream_rot") == 0) { g_opt_stream_rot = value; return PICHA_OK; }
     if (strcmp(key, "dpp") == 0) { g_opt_dpp = value; return PICHA_OK; }
+    if (strcmp(key, "chain_window_mb") == 0) { g_opt_chain_window_mb = value; return PICHA_OK; }
     return fail(PICHA_ERR_ARGUMENT, "unknown option %s", key);
 }
 long picha_hip_get_option(const char *key) {
@@ -940,6 +947,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "per_lane") == 0) return g_opt_per_lane;
     if (strcmp(key, "stream_rot") == 0) return g_opt_stream_rot;
     if (strcmp(key, "dpp") == 0) return g_opt_dpp;
+    if (strcmp(key, "chain_window_mb") == 0) return g_opt_chain_window_mb;
     return -1;
 }
 
@@ -1001,6 +1009,152 @@ int picha_hip_color_convert_device(int n, const picha_image *src, const picha_im
     return PICHA_OK;
 }
 
+// ---- chained colorConvert + resize ---------------------------------------------
+int picha_hip_convert_resize_device(int n, const picha_image *src, const picha_image *dst, int order, float r,
+                                    float g, float b, int filter, float filter_scale, void *stream) {
+    if (n < 0 || (n > 0 && (!src || !dst))) return fail(PICHA_ERR_ARGUMENT, "bad batch arguments");
+    if (order != PICHA_CONVERT_THEN_RESIZE && order != PICHA_RESIZE_THEN_CONVERT)
+        return fail(PICHA_ERR_ARGUMENT, "bad chain order");
+    if (filter < 0 || filter >= PICHA_NUM_FILTERS) return fail(PICHA_ERR_INVALID_FILTER, "invalid filter mode");
+    if (!(filter_scale > 0)) return fail(PICHA_ERR_INVALID_FILTER_WIDTH, "invalid filter width");
+    for (int i = 0; i < n; ++i) {
+        int rc = check_src(&src[i]);
+        if (rc) return rc;
+        rc = check_dst(&dst[i]);
+        if (rc) return rc;
+    }
+    if (n == 0) return PICHA_OK;
+    int dev;
+    int rc = current_device(&dev);
+    if (rc) return rc;
+    DeviceCtx *ctx = ctx_for(dev);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    long window_mb;
+    { std::lock_guard<std::mutex> lk(g_opt_mu); window_mb = g_opt_chain_window_mb; }
+    const size_t window = (size_t)std::max(1L, window_mb) << 20;
+    int i = 0;
+    while (i < n) {  // runs of equal geometry
+        int j = i + 1;
+        while (j < n && same_geometry(src[j], src[i]) && same_geometry(dst[j], dst[i])) ++j;
+        const picha_image &s0 = src[i], &d0 = dst[i];
+        if (s0.pixel == d0.pixel) {  // the convert step is the reference's payload copy: nothing to chain
+            rc = resize_group(ctx, src + i, dst + i, j - i, filter, filter_scale, s);
+        } else {  // (equal sizes still resize: a 1:1 resample is not the identity for every filter)
+            // the reference's intermediate image: newJsImage(w, h, pixel), stride = row_stride (src/picha.cc:119-133)
+            picha_image mid;
+            mid.pixel = order == PICHA_CONVERT_THEN_RESIZE ? d0.pixel : s0.pixel;
+            mid.width = order == PICHA_CONVERT_THEN_RESIZE ? s0.width : d0.width;
+            mid.height = order == PICHA_CONVERT_THEN_RESIZE ? s0.height : d0.height;
+            mid.stride = picha_row_stride(mid.width, mid.pixel);
+            mid.data = nullptr;
+            const size_t mid_bytes = align_up((size_t)mid.stride * mid.height, 256);
+            const int slice = (int)std::min<size_t>((size_t)(j - i), std::max<size_t>(1, window / mid_bytes));
+            std::lock_guard<std::mutex> lk(ctx->chain_mu);
+            rc = temp_acquire(ctx->chain, mid_bytes * slice, 0, s);
+            if (rc) return rc;
+            std::vector<picha_image> mids(slice, mid);
+            for (int k = 0; k < slice; ++k) mids[k].data = static_cast<uint8_t *>(ctx->chain.dev) + mid_bytes * k;
+            // slice by slice on one in-order stream: the second kernel reads what the first one just wrote while it
+            // is still in the Infinity Cache, and the buffer is reused by the next slice
+            for (int k = i; k < j && rc == PICHA_OK; k += slice) {
+                const int m = std::min(slice, j - k);
+                if (order == PICHA_CONVERT_THEN_RESIZE) {
+                    rc = convert_group(ctx, src + k, mids.data(), m, r, g, b, s);
+                    if (rc == PICHA_OK) rc = resize_group(ctx, mids.data(), dst + k, m, filter, filter_scale, s);
+                } else {
+                    rc = resize_group(ctx, src + k, mids.data(), m, filter, filter_scale, s);
+                    if (rc == PICHA_OK) rc = convert_group(ctx, mids.data(), dst + k, m, r, g, b, s);
+                }
+            }
+            int rc2 = temp_release(ctx->chain, s);
+            if (rc == PICHA_OK) rc = rc2;
+        }
+        if (rc) return rc;
+        i = j;
+    }
+    return PICHA_OK;
+}
+
+// ---- Image helpers on device images ----------------------------------------------
+int picha_hip_image_compare_device(int n, const picha_image *a, const picha_image *b, uint64_t *sum_abs_diff,
+                                   uint64_t *differing_bytes, void *stream) {
+    if (n < 0 || (n > 0 && (!a || !b))) return fail(PICHA_ERR_ARGUMENT, "bad batch arguments");
+    for (int i = 0; i < n; ++i) {
+        int rc = check_src(&a[i]);
+        if (rc) return rc;
+        rc = check_src(&b[i]);
+        if (rc) return rc;
+    }
+    if (n == 0) return PICHA_OK;
+    int dev;
+    int rc = current_device(&dev);
+    if (rc) return rc;
+    DeviceCtx *ctx = ctx_for(dev);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    std::lock_guard<std::mutex> lk(ctx->results_mu);
+    // device: [n][2] sums, then the two pointer tables; pinned mirror of the same layout
+    const size_t sums = align_up(sizeof(uint64_t) * 2 * (size_t)n, 256), tabs = sizeof(void *) * 2 * (size_t)n;
+    rc = temp_acquire(ctx->results, sums + tabs, sums + tabs, s);
+    if (rc) return rc;
+    uint8_t *dbase = static_cast<uint8_t *>(ctx->results.dev), *hbase = static_cast<uint8_t *>(ctx->results.host);
+    const void **htab = reinterpret_cast<const void **>(hbase + sums);
+    for (int i = 0; i < n; ++i) { htab[i] = a[i].data; htab[n + i] = b[i].data; }
+    HIP_TRY(hipMemsetAsync(dbase, 0, sums, s));
+    HIP_TRY(hipMemcpyAsync(dbase + sums, htab, tabs, hipMemcpyHostToDevice, s));
+    const void *const *dtab = reinterpret_cast<const void *const *>(dbase + sums);
+    std::vector<char> comparable(n, 0);
+    int i = 0;
+    while (i < n) {
+        int j = i + 1;
+        while (j < n && same_geometry(a[j], a[i]) && same_geometry(b[j], b[i])) ++j;
+        const picha_image &a0 = a[i], &b0 = b[i];
+        if (a0.width == b0.width && a0.height == b0.height && a0.pixel == b0.pixel) {  // lib/image.js:58, 66
+            CompareParams p{};
+            p.a_tab = dtab + i; p.b_tab = dtab + n + i;
+            p.a_stride = a0.stride; p.b_stride = b0.stride;
+            p.row_bytes = a0.width * kBytes[a0.pixel]; p.height = a0.height;
+            // >= 64 KB per block where the image allows it, and no more than 65535 row blocks
+            p.rows_per_block = std::max({1, (int)((65536 + (size_t)p.row_bytes - 1) / (size_t)p.row_bytes), (a0.height + 65534) / 65535});
+            p.n_images = j - i;
+            p.out = reinterpret_cast<unsigned long long *>(dbase) + 2 * (size_t)i;
+            HIP_TRY(launch_image_compare(p, s));
+            for (int k = i; k < j; ++k) comparable[k] = 1;
+        }
+        i = j;
+    }
+    HIP_TRY(hipMemcpyAsync(hbase, dbase, sums, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    const uint64_t *h = reinterpret_cast<const uint64_t *>(hbase);
+    for (int k = 0; k < n; ++k) {
+        if (sum_abs_diff) sum_abs_diff[k] = comparable[k] ? h[2 * k] : UINT64_MAX;
+        if (differing_bytes) differing_bytes[k] = comparable[k] ? h[2 * k + 1] : UINT64_MAX;
+    }
+    return PICHA_OK;  // the stream is idle: nothing pending on ctx->results
+}
+
+int picha_hip_image_copy_device(int n, const picha_image *src, const picha_image *dst, void *stream) {
+    if (n < 0 || (n > 0 && (!src || !dst))) return fail(PICHA_ERR_ARGUMENT, "bad batch arguments");
+    for (int i = 0; i < n; ++i) {
+        int rc = check_src(&src[i]);
+        if (rc) return rc;
+        rc = check_src(&dst[i]);
+        if (rc) return rc;
+        if (src[i].pixel != dst[i].pixel)
+            return fail(PICHA_ERR_PIXEL_MISMATCH, "can't copy pixels between different pixel types");
+    }
+    if (n == 0) return PICHA_OK;
+    int dev;
+    int rc = current_device(&dev);
+    if (rc) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    for (int i = 0; i < n; ++i) {  // lib/image.js:92-95
+        const size_t rw = (size_t)kBytes[src[i].pixel] * std::min(src[i].width, dst[i].width);
+        const int h = std::min(src[i].height, dst[i].height);
+        HIP_TRY(hipMemcpy2DAsync(dst[i].data, dst[i].stride, src[i].data, src[i].stride, rw, h, hipMemcpyDeviceToDevice, s));
+    }
+    return PICHA_OK;
+}
+
 // Validation of one host-pointer request (shared with the asynchronous dispatcher, dispatch.cpp).
 // Not part of the public header.
 int picha_hip_validate_host_op(int is_resize, const picha_image *src, const picha_image *dst, int filter,
@@ -1031,6 +1185,14 @@ int picha_hip_resize_batch(int n, const picha_image *src, const picha_image *dst
 }
 int picha_hip_color_convert_batch(int n, const picha_image *src, const picha_image *dst, float r, float g, float b) {
     return run_host(Op::Convert, n, src, dst, 0, 0, r, g, b);
+}
+int picha_hip_convert_resize(const picha_image *src, const picha_image *dst, int order, float r, float g, float b,
+                             int filter, float filter_scale) {
+    return run_host(Op::Chain, 1, src, dst, filter, filter_scale, r, g, b, order);
+}
+int picha_hip_convert_resize_batch(int n, const picha_image *src, const picha_image *dst, int order, float r, float g,
+                                   float b, int filter, float filter_scale) {
+    return run_host(Op::Chain, n, src, dst, filter, filter_scale, r, g, b, order);
 }
 
 // ---- device memory helpers --------------------------------------------------------------------------

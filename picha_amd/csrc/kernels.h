@@ -114,6 +114,18 @@ bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, in
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty);
 
+// ---- Image helpers on device images (lib/image.js:57-73) -------------------------------------------
+struct CompareParams {
+    const void *const *a_tab;  // per-image row-0 pointers (device arrays)
+    const void *const *b_tab;
+    int a_stride, b_stride;
+    int row_bytes, height;     // payload bytes per row (width * bytes per pixel)
+    int rows_per_block;
+    int n_images;
+    unsigned long long *out;   // [n_images][2]: sum |a - b| over payload bytes, number of differing bytes (pre-zeroed)
+};
+hipError_t launch_image_compare(const CompareParams &p, hipStream_t s);
+
 // ---- synthetic pixels ---------------------------------------------------------------------------
 hipError_t launch_fill_random(void *dev, size_t bytes, uint64_t seed, int sample_bytes, hipStream_t s);
 void fill_random_host(void *host, size_t bytes, uint64_t seed, int sample_bytes);

@@ -112,6 +112,22 @@ hipError_t launch_fill_random(void *dev, size_t bytes, uint64_t seed, int sample
     return hipGetLastError();
 }
 
+hipError_t launch_image_compare(const CompareParams &p, hipStream_t s) {
+    if (p.n_images <= 0 || p.height <= 0) return hipSuccess;
+    const int row_blocks = (p.height + p.rows_per_block - 1) / p.rows_per_block;
+    int done = 0;
+    while (done < p.n_images) {  // grid.z <= 65535
+        CompareParams q = p;
+        q.n_images = std::min(p.n_images - done, 65535);
+        q.a_tab = p.a_tab + done; q.b_tab = p.b_tab + done; q.out = p.out + 2 * (size_t)done;
+        image_compare_kernel<<<dim3(1, row_blocks, q.n_images), 256, 0, s>>>(q);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        done += q.n_images;
+    }
+    return hipSuccess;
+}
+
 // host twin of the generator
 void fill_random_host(void *host, size_t bytes, uint64_t seed, int sample_bytes) {
     uint8_t *d = static_cast<uint8_t *>(host);

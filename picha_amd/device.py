@@ -38,8 +38,8 @@ class DeviceBatch:
 
     def descriptors(self):
         """ctypes array of picha_image with DEVICE pointers (cached; tensor storage must not move)."""
-        if self._desc is None or self._desc[1] != self.tensor.data_ptr():
-            base = self.tensor.data_ptr()
+        if self._desc is None or self._desc[1] != self.tensor.data_ptr() + getattr(self, "_offset", 0):
+            base = self.tensor.data_ptr() + getattr(self, "_offset", 0)
             arr = (N.CImage * self.n)()
             p = N.pixel_index(self.pixel)
             for i in range(self.n):
@@ -58,8 +58,48 @@ class DeviceBatch:
     def image_host(self, i):
         """Download image i as a host `Image`."""
         from .image import Image
-        data = self.tensor[i, : self.height * self.stride].cpu().numpy().copy()
+        off = getattr(self, "_offset", 0)
+        span = (self.height - 1) * self.stride + self.width * N.PIXEL_BYTES[self.pixel]
+        data = self.tensor[i, off : off + span].cpu().numpy().copy()
         return Image(width=self.width, height=self.height, pixel=self.pixel, stride=self.stride, data=data)
+
+    # ---- Image helpers on the device (reference lib/image.js:57-96) -------------------------------------
+    def sub_view(self, x, y, w, h):
+        """Image.prototype.subView for every image of the batch: same storage and stride, offset origin."""
+        v = DeviceBatch.__new__(DeviceBatch)
+        v.n, v.width, v.height, v.pixel, v.stride, v.pitch = self.n, int(w), int(h), self.pixel, self.stride, self.pitch
+        v.tensor, v._desc = self.tensor, None
+        v._offset = getattr(self, "_offset", 0) + y * self.stride + x * N.PIXEL_BYTES[self.pixel]
+        return v
+
+    def _compare(self, other):
+        if self.n != other.n:
+            raise N.PichaError("batches differ in length")
+        s = (ctypes.c_uint64 * self.n)()
+        c = (ctypes.c_uint64 * self.n)()
+        with torch.cuda.device(self.tensor.device):
+            N.check(N.lib().picha_hip_image_compare_device(self.n, self.descriptors(), other.descriptors(), s, c,
+                                                           _stream(self.tensor)))
+        return list(s), list(c)
+
+    def equal_pixels(self, other):
+        """Image.prototype.equalPixels per image -> list of bool (False where geometry or format differ)."""
+        _, c = self._compare(other)
+        return [v == 0 for v in c]
+
+    def avg_channel_diff(self, other):
+        """Image.prototype.avgChannelDiff per image -> list of float (255 where geometry or format differ)."""
+        s, _ = self._compare(other)
+        rw = self.width * N.PIXEL_BYTES[self.pixel]
+        return [255 if v == 0xFFFFFFFFFFFFFFFF else v / (self.height * rw) for v in s]
+
+    def copy_to(self, target):
+        """Image.prototype.copy per image: the common top-left rectangle, payload bytes only."""
+        if self.n != target.n:
+            raise N.PichaError("batches differ in length")
+        with torch.cuda.device(self.tensor.device):
+            N.check(N.lib().picha_hip_image_copy_device(self.n, self.descriptors(), target.descriptors(), _stream(self.tensor)))
+        return target
 
     def upload(self, i, image):
         assert (image.width, image.height, image.pixel, image.stride) == (self.width, self.height, self.pixel, self.stride)
@@ -104,6 +144,26 @@ def color_convert_batch(src, pixel, weights=None, out=None):
         out = DeviceBatch(src.n, src.width, src.height, pixel, device=src.tensor.device)
     with torch.cuda.device(src.tensor.device):
         N.check(N.lib().picha_hip_color_convert_device(src.n, src.descriptors(), out.descriptors(), r, g, b, _stream(src.tensor)))
+    return out
+
+
+def convert_resize_batch(src, pixel, dst_width, dst_height, weights=None, filter=None, filter_scale=None, order=0, out=None):
+    """colorConvert and resize chained on the device (picha_hip_convert_resize_device): order 0 = convert first."""
+    from .api import _resize_options, color_settings
+    if N.pixel_index(pixel) < 0:
+        raise N.PichaError("expected pixel mode")
+    o = {}
+    if filter is not None:
+        o["filter"] = filter
+    if filter_scale is not None:
+        o["filterScale"] = filter_scale
+    ftag, fscale = _resize_options(o)
+    r, g, b = weights if weights is not None else color_settings()
+    if out is None:
+        out = DeviceBatch(src.n, dst_width, dst_height, pixel, device=src.tensor.device)
+    with torch.cuda.device(src.tensor.device):
+        N.check(N.lib().picha_hip_convert_resize_device(src.n, src.descriptors(), out.descriptors(), int(order), r, g, b,
+                                                        ftag, fscale, _stream(src.tensor)))
     return out
 
 

@@ -1,0 +1,169 @@
+"""GPU parity for the rows next to the path:
+
+  * colorConvert + resize chained on the device (picha_hip_convert_resize*) must equal the two reference
+    operations run back to back (oracle colorConvert -> oracle resize, or the other order), bit for bit;
+  * Image.equalPixels / avgChannelDiff / copy / subView on device images (lib/image.js:57-96) must equal the
+    reference's byte-wise definitions computed with numpy on the host.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+
+import picha_amd as picha
+from picha_amd import _native as N
+from util import PIXELS, max_code_diff, oracle_convert, oracle_resize, payload, rand_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _c(img):
+    return N.CImage(img.data.ctypes.data, img.stride, img.width, img.height, N.pixel_index(img.pixel))
+
+
+def _chain_oracle(img, pixel, w, h, order, weights, filter, fscale):
+    if order == 0:
+        return oracle_resize(oracle_convert(img, pixel, weights), w, h, filter, fscale)
+    return oracle_convert(oracle_resize(img, w, h, filter, fscale), pixel, weights)
+
+
+CASES = [
+    # src pixel, dst pixel, src size, dst size, filter, filterScale
+    ("rgb", "grey", (97, 61), (13, 9), "lanczos", 1.0),          # cfg3's pair at a small size
+    ("rgba", "greya", (64, 48), (32, 24), "cubic", 0.70),        # streaming kernel in the chain
+    ("grey", "rgba", (31, 17), (47, 40), "triangle", 1.0),       # upscale
+    ("r16g16b16a16", "rgb", (40, 30), (20, 15), "mitchel", 1.0), # 16 -> 8 bit
+    ("greya", "r16g16b16", (23, 19), (11, 10), "box", 1.0),      # the 2 -> 3 channel map quirk, ring aliasing
+    ("rgba", "r16g16b16a16", (50, 20), (50, 20), "catmulrom", 1.0),  # same size: still resampled
+]
+
+
+@pytest.mark.parametrize("order", [0, 1])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: "%s-%s-%s" % (c[0], c[1], c[4]))
+def test_convert_resize_chain_equals_two_reference_calls(case, order):
+    sp, dp, (sw, sh), (dw, dh), filt, fscale = case
+    rng = np.random.default_rng(hash((sp, dp, order)) & 0xFFFF)
+    weights = picha.color_settings(0.2, 0.7, 0.1)
+    img = rand_image(rng, sw, sh, sp, pad=4)
+    want = _chain_oracle(img, dp, dw, dh, order, weights, filt, fscale)
+    got = picha.convertResizeSync(img, {"pixel": dp, "width": dw, "height": dh, "filter": filt, "filterScale": fscale,
+                                        "redWeight": 0.2, "greenWeight": 0.7, "blueWeight": 0.1,
+                                        "order": "resizeFirst" if order else "convertFirst"})
+    assert (got.width, got.height, got.pixel, got.stride) == (dw, dh, dp, want.stride)
+    assert np.array_equal(payload(got), payload(want)), "max code diff %d" % max_code_diff(got, want)
+
+
+def test_convert_resize_chain_same_format_is_plain_resize_and_errors_match():
+    rng = np.random.default_rng(5)
+    img = rand_image(rng, 40, 30, "rgb")
+    got = picha.convertResizeSync(img, {"pixel": "rgb", "width": 20, "height": 15})
+    assert np.array_equal(payload(got), payload(oracle_resize(img, 20, 15)))
+    with pytest.raises(picha.PichaError, match="expected pixel mode"):
+        picha.convertResizeSync(img, {"width": 20, "height": 15})
+    with pytest.raises(picha.PichaError, match="invalid dimensions"):
+        picha.convertResizeSync(img, {"pixel": "grey", "width": 0, "height": 15})
+    with pytest.raises(picha.PichaError, match="invalid filter mode"):
+        picha.convertResizeSync(img, {"pixel": "grey", "width": 4, "height": 4, "filter": "nearest"})
+    L = N.lib()
+    src, dst = _c(img), _c(picha.Image(width=4, height=4, pixel="grey"))
+    assert L.picha_hip_convert_resize(ctypes.byref(src), ctypes.byref(dst), 7, 0.3, 0.6, 0.1, 0, 1.0) == -10
+
+
+def test_convert_resize_device_batch_slices_through_the_intermediate_window():
+    """A batch larger than the intermediate window is processed in slices; every image must still be right."""
+    import torch
+    from picha_amd.device import DeviceBatch, convert_resize_batch
+    L = N.lib()
+    n, sw, sh, dw, dh = 12, 640, 360, 128, 96
+    src = DeviceBatch(n, sw, sh, "rgb").fill_random(77)
+    old = L.picha_hip_get_option(b"chain_window_mb")
+    try:
+        N.check(L.picha_hip_set_option(b"chain_window_mb", 1))   # 640*360 grey = 230 KB -> 4 images per slice
+        out = convert_resize_batch(src, "grey", dw, dh, filter="lanczos")
+        torch.cuda.synchronize()
+    finally:
+        N.check(L.picha_hip_set_option(b"chain_window_mb", old))
+    for i in (0, 3, 4, 7, 11):
+        want = _chain_oracle(src.image_host(i), "grey", dw, dh, 0, None, "lanczos", 1.0)
+        assert np.array_equal(payload(out.image_host(i)), payload(want)), i
+
+
+def _host_stats(a, b):
+    pa, pb = payload(a).astype(np.int64), payload(b).astype(np.int64)
+    return int(np.abs(pa - pb).sum()), int((pa != pb).sum())
+
+
+@pytest.mark.parametrize("pixel", ["rgba", "rgb", "grey", "r16g16b16"])
+def test_device_image_compare_matches_reference_definitions(pixel):
+    import torch
+    from picha_amd.device import DeviceBatch
+    rng = np.random.default_rng(11)
+    n, w, h = 5, 211, 37
+    a, b = DeviceBatch(n, w, h, pixel), DeviceBatch(n, w, h, pixel)
+    imgs_a, imgs_b = [], []
+    for i in range(n):
+        ia = rand_image(rng, w, h, pixel)
+        ib = picha.Image(width=w, height=h, pixel=pixel, stride=ia.stride, data=ia.data.copy())
+        if i == 1:                                   # identical payload, different PADDING: still equal
+            bpp = N.PIXEL_BYTES[pixel]
+            if ib.stride > w * bpp:
+                ib.data.reshape(h, ib.stride)[:, w * bpp:] ^= 0xFF
+        elif i == 2:                                 # one byte differs
+            ib.data[7 * ib.stride + 5] ^= 0x40
+        elif i >= 3:                                 # everything differs
+            ib = rand_image(rng, w, h, pixel)
+        a.upload(i, ia); b.upload(i, ib)
+        imgs_a.append(ia); imgs_b.append(ib)
+    torch.cuda.synchronize()
+    eq = a.equal_pixels(b)
+    avg = a.avg_channel_diff(b)
+    for i in range(n):
+        s, c = _host_stats(imgs_a[i], imgs_b[i])
+        assert eq[i] == (c == 0) == imgs_a[i].equalPixels(imgs_b[i])
+        assert avg[i] == s / (h * w * N.PIXEL_BYTES[pixel]) == imgs_a[i].avgChannelDiff(imgs_b[i])
+    assert eq[:3] == [True, True, False]
+
+
+def test_device_image_compare_subviews_unaligned_and_mismatched_geometry():
+    import torch
+    from picha_amd.device import DeviceBatch
+    rng = np.random.default_rng(12)
+    w, h = 90, 40
+    a, b = DeviceBatch(2, w, h, "rgb"), DeviceBatch(2, w, h, "rgb")
+    imgs = [rand_image(rng, w, h, "rgb") for _ in range(4)]
+    for i in range(2):
+        a.upload(i, imgs[i]); b.upload(i, imgs[2 + i])
+    torch.cuda.synchronize()
+    # rgb subviews at x = 1 vs x = 2: rows at byte offsets 3 and 6 (not congruent mod 4) -> the byte path
+    va, vb = a.sub_view(1, 3, 50, 20), b.sub_view(2, 5, 50, 20)
+    avg = va.avg_channel_diff(vb)
+    for i in range(2):
+        ha, hb = imgs[i].subView(1, 3, 50, 20), imgs[2 + i].subView(2, 5, 50, 20)
+        assert avg[i] == ha.avgChannelDiff(hb)
+    # congruent but unaligned rows -> head / dword / tail path
+    va, vb = a.sub_view(1, 0, 77, 9), b.sub_view(5, 2, 77, 9)
+    for i, v in enumerate(va.avg_channel_diff(vb)):
+        assert v == imgs[i].subView(1, 0, 77, 9).avgChannelDiff(imgs[2 + i].subView(5, 2, 77, 9))
+    # different geometry: the reference answers 255 / false without looking at pixels (lib/image.js:58, 66)
+    other = a.sub_view(0, 0, 50, 21)
+    assert a.sub_view(0, 0, 50, 20).avg_channel_diff(other) == [255, 255]
+    assert a.sub_view(0, 0, 50, 20).equal_pixels(other) == [False, False]
+
+
+def test_device_image_copy_is_the_common_rectangle_payload_only():
+    import torch
+    from picha_amd.device import DeviceBatch
+    rng = np.random.default_rng(13)
+    src, dst = DeviceBatch(2, 33, 21, "greya"), DeviceBatch(2, 20, 30, "greya")
+    s_imgs = [rand_image(rng, 33, 21, "greya") for _ in range(2)]
+    d_imgs = [rand_image(rng, 20, 30, "greya") for _ in range(2)]
+    for i in range(2):
+        src.upload(i, s_imgs[i]); dst.upload(i, d_imgs[i])
+    src.copy_to(dst)
+    torch.cuda.synchronize()
+    for i in range(2):
+        s_imgs[i].copy(d_imgs[i])                      # the host mirror of lib/image.js:89-96
+        got = dst.image_host(i)
+        assert np.array_equal(got.data[: (30 - 1) * got.stride + 40], d_imgs[i].data[: (30 - 1) * got.stride + 40])
+    with pytest.raises(N.PichaError, match="can't copy pixels between different pixel types"):
+        src.copy_to(DeviceBatch(2, 20, 30, "rgb"))
