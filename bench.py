@@ -32,6 +32,10 @@ WORKLOADS = {
     "cfg3b_4k_grey_to_512_lanczos": (256, 3840, 2160, "grey", 512, 512, {"filter": "lanczos"}),
     # colour convert: dst size == src size, opts names the destination format
     "cfg3a_4k_rgb_to_grey": (256, 3840, 2160, "rgb", 3840, 2160, {"convert": "grey"}),
+    # cfg3 as ONE call: colorConvert then resize chained on the device (picha_hip_convert_resize_device); algorithmic
+    # bytes are those of a fused operation (source read + destination written), although the grey
+    # intermediate is materialised slice by slice
+    "cfg3_4k_rgb_to_grey_to_512_lanczos_chained": (256, 3840, 2160, "rgb", 512, 512, {"convert": "grey", "filter": "lanczos", "chain": True}),
     "cc_4k_rgba_to_rgba16": (64, 3840, 2160, "rgba", 3840, 2160, {"convert": "r16g16b16a16"}),
     "cfg5_8k_rgba16_to_1080p_mitchel": (32, 7680, 4320, "r16g16b16a16", 1920, 1080, {"filter": "mitchel"}),
 }
@@ -129,7 +133,15 @@ def main():
     convert_to = opts.get("convert")
     dst_pixel = convert_to or pixel
     dst = DeviceBatch(n, dw, dh, dst_pixel, device=dev)
-    if convert_to:
+    chained = bool(opts.get("chain"))
+    if chained:
+        from picha_amd.device import convert_resize_batch
+
+        class _ChainPlan:
+            def run(self):
+                convert_resize_batch(src, convert_to, dw, dh, filter=opts.get("filter"), filter_scale=opts.get("filterScale"), out=dst)
+        plan = _ChainPlan()
+    elif convert_to:
         from picha_amd.device import color_convert_batch
 
         class _ConvertPlan:
@@ -148,6 +160,8 @@ def main():
         plan.run()
     torch.cuda.synchronize()
     kernel = "color_convert_kernel<%s->%s>" % (pixel, convert_to) if convert_to else N.lib().picha_hip_last_kernel().decode()
+    if chained:
+        kernel += " + " + N.lib().picha_hip_last_kernel().decode()
 
     # per-launch durations from events on the launch stream (torch's current stream)
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -170,7 +184,7 @@ def main():
 
     # the other numerics flavour, timed the same way on rank 0's batch (reported, not the headline)
     other = None
-    if rank == 0 and world == 1 and not convert_to:
+    if rank == 0 and world == 1 and (chained or not convert_to):
         other_name = "exact" if numerics == "fma" else "fma"
         set_opt("numerics", 1 if other_name == "fma" else 0)
         for _ in range(max(1, args.warmup)):
@@ -199,7 +213,10 @@ def main():
         got = dst.image_host(0)
         filt = opts.get("filter", "cubic")
         fscale = opts.get("filterScale", 1.0 if "filter" in opts else 0.70)
-        if convert_to:
+        if chained:
+            mid, _ = oracle.color_convert(img.data, sw, sh, pixel, convert_to)
+            exp, _ = oracle.resize(mid, sw, sh, convert_to, dw, dh, filt, fscale)
+        elif convert_to:
             exp, _ = oracle.color_convert(img.data, sw, sh, pixel, convert_to)
         else:
             exp, _ = oracle.resize(img.data, sw, sh, pixel, dw, dh, filt, fscale)

@@ -126,6 +126,7 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "row_chunks" 0 = auto, else number of row chunks per image for the fused kernels
  *   "stream_rot" 0 = auto, 1 / 2 = force the rotating-accumulator / unrolled variant of the streaming kernel
  *   "dpp"        1 = use the cross-lane pixel-sharing streaming kernel where it applies (rgba, 2x, 5 taps)
+ *   "chain_window_mb"  size of the intermediate buffer of picha_hip_convert_resize* in MB (default 4096)
  * Returns PICHA_ERR_ARGUMENT for an unknown key.
  */
 int picha_hip_set_option(const char *key, long value);
@@ -188,8 +189,9 @@ int picha_hip_color_convert_device(int n, const picha_image *src, const picha_im
 
 /* ---- next to the path: colorConvert and resize chained on the device -----------
  * What a picha user writes as  resize(colorConvert(image, {pixel}), {width, height})  — or the other way
- * round — as ONE call: both kernels run back to back on the device, the intermediate image never crosses
- * PCIe and is produced in slices sized for the 256 MB Infinity Cache.  Results are bit-identical to the two
+ * round — as ONE call: both kernels run back to back on the device and the intermediate image never crosses
+ * PCIe (it lives in a reusable HBM buffer of at most "chain_window_mb" MB, default 4096; larger batches go
+ * through it in slices).  Results are bit-identical to the two
  * reference calls in that order (the intermediate is quantised to the destination sample type in between,
  * exactly as the reference's intermediate Buffer is).  src and dst may differ in pixel format AND size:
  *   PICHA_CONVERT_THEN_RESIZE  colorConvert src to dst->pixel at the source size (src/colorconvert.cc:171-188),

@@ -64,7 +64,10 @@ long g_opt_numerics = [] {
     const char *e = getenv("PICHA_HIP_NUMERICS");
     return (e && strcmp(e, "fma") == 0) ? 1L : 0L;
 }();
-long g_opt_chain_window_mb = 96;  // intermediate bytes produced per slice of a chained convert+resize (fits the 256 MB MALL)
+// intermediate bytes per slice of a chained convert+resize.  Slices small enough to stay in the 256 MB Infinity Cache
+// were measured SLOWER (r01, profiles/r01_chain_window.txt: 96 MB 2.91 ms vs unsliced 2.49 ms for cfg3 — the short
+// launches do not fill the chip), so the window only bounds memory.
+long g_opt_chain_window_mb = 4096;
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 long g_opt_stream_rot = 0;  // 0 auto, 1 force the rotating-accumulator streaming variant, 2 force the unrolled one
 long g_opt_dpp = 0;         // 0 auto, 1 prefer / 2 forbid the cross-lane pixel-sharing streaming kernel
@@ -1054,8 +1057,7 @@ int picha_hip_convert_resize_device(int n, const picha_image *src, const picha_i
             if (rc) return rc;
             std::vector<picha_image> mids(slice, mid);
             for (int k = 0; k < slice; ++k) mids[k].data = static_cast<uint8_t *>(ctx->chain.dev) + mid_bytes * k;
-            // slice by slice on one in-order stream: the second kernel reads what the first one just wrote while it
-            // is still in the Infinity Cache, and the buffer is reused by the next slice
+            // slice by slice on one in-order stream; the buffer is reused by the next slice
             for (int k = i; k < j && rc == PICHA_OK; k += slice) {
                 const int m = std::min(slice, j - k);
                 if (order == PICHA_CONVERT_THEN_RESIZE) {

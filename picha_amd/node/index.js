@@ -19,5 +19,8 @@ exports.colorConvert = function (src, opt, cb) { native.colorConvert(src, opt, w
 exports.colorConvertSync = function (img, opt) { return new Image(native.colorConvertSync(img, opt)); };
 
 // outside the drop-in surface
+// resizeSync(colorConvertSync(img, opt), opt) — or the other order with opt.order === 'resizeFirst' — in one device
+// round trip: the intermediate image never leaves the GPU; same result as the two calls
+exports.convertResizeSync = function (img, opt) { return new Image(native.convertResizeSync(img, opt)); };
 exports.hipDeviceCount = native.hipDeviceCount;
 exports.hipLastKernel = native.hipLastKernel;

@@ -137,7 +137,8 @@ static napi_value new_js_image(napi_env env, int w, int h, int pixel, picha_imag
 
 /* ---- one operation, shared by the sync and async forms --------------------------------------- */
 typedef struct op_ctx {
-    int is_resize;
+    int is_resize; /* 1 resize, 0 colorConvert, 2 both chained on the device (convertResizeSync, outside the drop-in surface) */
+    int order;     /* chained: PICHA_CONVERT_THEN_RESIZE or PICHA_RESIZE_THEN_CONVERT */
     picha_image src, dst;
     int filter;
     float filter_scale;
@@ -150,7 +151,9 @@ typedef struct op_ctx {
 } op_ctx;
 
 static void run_op(op_ctx *c) {
-    if (c->is_resize) c->status = picha_hip_resize(&c->src, &c->dst, c->filter, c->filter_scale);
+    if (c->is_resize == 2)
+        c->status = picha_hip_convert_resize(&c->src, &c->dst, c->order, c->cs[0], c->cs[1], c->cs[2], c->filter, c->filter_scale);
+    else if (c->is_resize) c->status = picha_hip_resize(&c->src, &c->dst, c->filter, c->filter_scale);
     else c->status = picha_hip_color_convert(&c->src, &c->dst, c->cs[0], c->cs[1], c->cs[2]);
     if (c->status != PICHA_OK) {
         const char *m = picha_hip_last_error(); /* thread-local: read it on the thread that failed */
@@ -200,9 +203,28 @@ static void async_call_js(napi_env env, napi_value cb, void *context, void *data
 static int prepare(napi_env env, napi_value img, napi_value opts, op_ctx *c, napi_value *src_data, napi_value *dst_obj) {
     c->src = to_native_image(env, img, src_data);
     if (!c->src.data) { throw_msg(env, "invalid image"); return 0; }
-    if (c->is_resize) {
-        int width = to_uint32_as_int(env, get_prop(env, opts, "width"));
-        int height = to_uint32_as_int(env, get_prop(env, opts, "height"));
+    int to_pixel = c->src.pixel, width = c->src.width, height = c->src.height;
+    if (c->is_resize != 1) {
+        to_pixel = pixel_from_value(env, get_prop(env, opts, "pixel"));
+        if (to_pixel == PICHA_INVALID_PIXEL) { throw_msg(env, "expected pixel mode"); return 0; }
+        /* getSettings (src/colorconvert.cc:6-22): NumberValue of each weight, NaN keeps the default */
+        const char *names[3] = {"redWeight", "greenWeight", "blueWeight"};
+        double w[3];
+        for (int i = 0; i < 3; ++i) {
+            napi_value num;
+            w[i] = NAN;
+            if (napi_coerce_to_number(env, get_prop(env, opts, names[i]), &num) != napi_ok ||
+                napi_get_value_double(env, num, &w[i]) != napi_ok) {
+                napi_value exc;
+                napi_get_and_clear_last_exception(env, &exc);
+                w[i] = NAN;
+            }
+        }
+        picha_color_settings(w[0], w[1], w[2], c->cs);
+    }
+    if (c->is_resize != 0) {
+        width = to_uint32_as_int(env, get_prop(env, opts, "width"));
+        height = to_uint32_as_int(env, get_prop(env, opts, "height"));
         if (width <= 0 || height <= 0) { throw_msg(env, "invalid dimensions"); return 0; }
         /* getResizeOptions (src/resize.cc:179-198) */
         napi_value f = get_prop(env, opts, "filter"), fs = get_prop(env, opts, "filterScale");
@@ -226,26 +248,18 @@ static int prepare(napi_env env, napi_value img, napi_value opts, op_ctx *c, nap
         }
         int rc = picha_resize_options(has_filter, tag, has_scale, scale, &c->filter, &c->filter_scale);
         if (rc != PICHA_OK) { throw_msg(env, picha_hip_strerror(rc)); return 0; }
-        *dst_obj = new_js_image(env, width, height, c->src.pixel, &c->dst);
-    } else {
-        int to_pixel = pixel_from_value(env, get_prop(env, opts, "pixel"));
-        if (to_pixel == PICHA_INVALID_PIXEL) { throw_msg(env, "expected pixel mode"); return 0; }
-        /* getSettings (src/colorconvert.cc:6-22): NumberValue of each weight, NaN keeps the default */
-        const char *names[3] = {"redWeight", "greenWeight", "blueWeight"};
-        double w[3];
-        for (int i = 0; i < 3; ++i) {
-            napi_value num;
-            w[i] = NAN;
-            if (napi_coerce_to_number(env, get_prop(env, opts, names[i]), &num) != napi_ok ||
-                napi_get_value_double(env, num, &w[i]) != napi_ok) {
-                napi_value exc;
-                napi_get_and_clear_last_exception(env, &exc);
-                w[i] = NAN;
-            }
-        }
-        picha_color_settings(w[0], w[1], w[2], c->cs);
-        *dst_obj = new_js_image(env, c->src.width, c->src.height, to_pixel, &c->dst);
     }
+    if (c->is_resize == 2) { /* opts.order: 'resizeFirst' resizes in the source format, then converts */
+        napi_value o = get_prop(env, opts, "order");
+        napi_valuetype t;
+        char buf[32];
+        size_t len;
+        c->order = PICHA_CONVERT_THEN_RESIZE;
+        if (napi_typeof(env, o, &t) == napi_ok && t == napi_string &&
+            napi_get_value_string_utf8(env, o, buf, sizeof buf, &len) == napi_ok && strcmp(buf, "resizeFirst") == 0)
+            c->order = PICHA_RESIZE_THEN_CONVERT;
+    }
+    *dst_obj = new_js_image(env, width, height, to_pixel, &c->dst);
     return *dst_obj != NULL;
 }
 
@@ -309,6 +323,9 @@ static napi_value js_resize_sync(napi_env env, napi_callback_info info) { return
 static napi_value js_color_convert(napi_env env, napi_callback_info info) { return do_async(env, info, 0, "expected: colorConvert(image, opts, cb)"); }
 static napi_value js_color_convert_sync(napi_env env, napi_callback_info info) { return do_sync(env, info, 0, "expected: colorConvertSync(image, opts)"); }
 
+/* outside the drop-in surface: colorConvertSync + resizeSync in one device round trip (include/picha_hip.h, 8f row 2) */
+static napi_value js_convert_resize_sync(napi_env env, napi_callback_info info) { return do_sync(env, info, 2, "expected: convertResizeSync(image, opts)"); }
+
 /* extras outside the drop-in surface */
 static napi_value js_device_count(napi_env env, napi_callback_info info) {
     napi_value v;
@@ -328,6 +345,7 @@ static napi_value init(napi_env env, napi_value exports) {
     struct { const char *name; napi_callback cb; } methods[] = {
         {"resize", js_resize}, {"resizeSync", js_resize_sync},
         {"colorConvert", js_color_convert}, {"colorConvertSync", js_color_convert_sync},
+        {"convertResizeSync", js_convert_resize_sync},
         {"hipDeviceCount", js_device_count}, {"hipLastKernel", js_last_kernel},
     };
     for (size_t i = 0; i < sizeof methods / sizeof methods[0]; ++i) {

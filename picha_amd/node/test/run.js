@@ -89,6 +89,10 @@ test('argument errors', () => {
 	throwsMsg(() => picha.resizeSync(img, { width: 2, height: 2, filterScale: 'wide' }), 'invalid filter width');
 	throwsMsg(() => picha.colorConvertSync(img, {}), 'expected pixel mode');
 	throwsMsg(() => picha.colorConvertSync(img, { pixel: 'cmyk' }), 'expected pixel mode');
+	throwsMsg(() => picha.convertResizeSync(img), 'expected: convertResizeSync(image, opts)');
+	throwsMsg(() => picha.convertResizeSync(img, { width: 2, height: 2 }), 'expected pixel mode');
+	throwsMsg(() => picha.convertResizeSync(img, { pixel: 'grey', height: 2 }), 'invalid dimensions');
+	throwsMsg(() => picha.convertResizeSync(img, { pixel: 'grey', width: 2, height: 2, filter: 'nope' }), 'invalid filter mode');
 	assert.deepStrictEqual(Object.keys(picha.catalog), []);
 });
 
@@ -131,6 +135,15 @@ if (!haveGpu) {
 				done();
 			} catch (e) { done(e); }
 		});
+	});
+	test('convertResizeSync equals the two calls in either order (one device round trip)', () => {
+		const a = picha.convertResizeSync(image, { pixel: 'grey', width: 32, height: 24, filter: 'lanczos' });
+		const b = picha.resizeSync(picha.colorConvertSync(image, { pixel: 'grey' }), { width: 32, height: 24, filter: 'lanczos' });
+		assert.strictEqual(a.pixel, 'grey'); assert.strictEqual(a.width, 32); assert.strictEqual(a.height, 24);
+		assert(a.equalPixels(b));
+		const c = picha.convertResizeSync(image, { pixel: 'rgba', width: 32, height: 24, order: 'resizeFirst' });
+		const d = picha.colorConvertSync(picha.resizeSync(image, { width: 32, height: 24 }), { pixel: 'rgba' });
+		assert(c.equalPixels(d));
 	});
 	test('resize: every filter and a 16-bit format run', () => {
 		const big = new Image({ width: 64, height: 48, pixel: 'r16g16b16a16' });

@@ -1,6 +1,6 @@
 #!/bin/bash
 out=gpurun_out/bench_workloads.txt; : > $out
-for w in cfg2_4k_rgba_to_1080p_cubic cfg2_4k_rgba_to_1080p_cubic_scale1 cfg1_640x480_rgba_to_320x240 cfg3a_4k_rgb_to_grey cfg3b_4k_grey_to_512_lanczos cfg5_8k_rgba16_to_1080p_mitchel cc_4k_rgba_to_rgba16; do
+for w in cfg2_4k_rgba_to_1080p_cubic cfg2_4k_rgba_to_1080p_cubic_scale1 cfg1_640x480_rgba_to_320x240 cfg3a_4k_rgb_to_grey cfg3b_4k_grey_to_512_lanczos cfg3_4k_rgb_to_grey_to_512_lanczos_chained cfg5_8k_rgba16_to_1080p_mitchel cc_4k_rgba_to_rgba16; do
   timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $w "$@" 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:

@@ -17,3 +17,18 @@ for (w, h, dw, dh, pix) in [(640, 480, 320, 240, 'rgba'), (3840, 2160, 1920, 108
     for _ in range(n): picha_amd.colorConvertSync(img, {'pixel': 'grey'})
     dt = (time.perf_counter() - t0) / n
     print('colorConvertSync %dx%d %s -> grey : %.3f ms/call' % (w, h, pix, dt * 1e3))
+
+# cfg3's pair through the host API: two calls (the grey 4K intermediate crosses PCIe twice) vs one chained call
+img = picha_amd.Image(width=3840, height=2160, pixel='rgb', data=rng.integers(0, 256, 2160 * 3840 * 3, dtype=np.uint8))
+o = {'pixel': 'grey', 'width': 512, 'height': 512, 'filter': 'lanczos'}
+for _ in range(3):
+    picha_amd.convertResizeSync(img, o); picha_amd.resizeSync(picha_amd.colorConvertSync(img, o), o)
+n = 30
+t0 = time.perf_counter()
+for _ in range(n): two = picha_amd.resizeSync(picha_amd.colorConvertSync(img, o), o)
+dt2 = (time.perf_counter() - t0) / n
+t0 = time.perf_counter()
+for _ in range(n): one = picha_amd.convertResizeSync(img, o)
+dt1 = (time.perf_counter() - t0) / n
+assert one.equalPixels(two)
+print('4K rgb -> grey -> 512x512 lanczos: colorConvertSync + resizeSync %.3f ms, convertResizeSync %.3f ms (identical pixels)' % (dt2 * 1e3, dt1 * 1e3))
