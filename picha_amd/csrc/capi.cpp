@@ -478,9 +478,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) fused_ok = false;
         if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % al) fused_ok = false;
     }
-    // sub-dword pixels fetched as dwords get their window aligned down (up to 3 pixels): leave room for it
-    const int align_room = (kBytes[pixel] % 4 == 0 || ax->host.taps <= 3) ? 0 : ((kBytes[pixel] % 2) ? 3 : 1);
-    int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps + align_room, pixel);
+    int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps, pixel);  // includes alignment room where needed
     const DeviceAxis::XTable *xt = nullptr;
     if (fused_ok && opt_per_lane != 1) {
         // integer decimation / interpolation step of the tap windows

@@ -78,6 +78,19 @@ int fused_x_bucket(int x_taps, int pixel);
 // True if the kernel for that bucket fetches a sub-dword-pixel span as whole dwords: the host must then
 // keep every lane's window inside its row (shifted, zero-padded in front).
 bool fused_x_bytespan(int x_taps_bucket, int pixel);
+// Sub-dword pixel formats (bytes per pixel 1, 2, 3, 6) in the single-output span kernels, two ways to fetch a window
+// of `x_taps_bucket` pixels as whole dwords:
+//   rotated   aligned dword loads from the dword holding the window's first byte, then v_alignbyte_b32 by the lane's
+//             byte phase: any window start, costs one extra dword and ceil(bytes/4) rotate instructions per row;
+//   aligned   the host moves each window's start down to a 4-byte boundary of the row (up to 3 extra tap slots for
+//             1- and 3-byte pixels, 1 for 2- and 6-byte pixels) and pads the tap count so the window is whole dwords.
+// Measured r01 (scripts/survey_formats.py): rotation wins for 1- and 3-byte pixels with short windows (rgb 3x down
+// -16 %, rgb 2x up -49 %) and loses by ~10 % on long ones and on 2-/6-byte pixels, hence this rule.
+constexpr bool span_rotate(int bytes_per_pixel, int x_taps_bucket) {
+    return bytes_per_pixel % 4 == 0 ? false
+         : bytes_per_pixel % 2 == 1 ? x_taps_bucket <= 20
+                                    : (x_taps_bucket <= 3 || (x_taps_bucket * bytes_per_pixel) % 4 != 0);
+}
 
 // Which formats the span/stream kernels unpack through the denormal form in the reference flavour (then the x weights
 // must be scaled by 2^22).  Measured r01 (profiles/r01_ab_denorm_unpack.txt): 16-bit samples −5.5 % kernel time (one

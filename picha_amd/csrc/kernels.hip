@@ -60,18 +60,19 @@ int fused_y_pad(int y_taps) { return y_taps <= 8 ? 8 : (y_taps <= 16 ? 16 : 32);
 int fused_x_bucket(int x_taps, int pixel) {
     static const int buckets[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 36};
     const int bpp = pixel_channels(pixel) * (pixel_is16(pixel) ? 2 : 1);
-    for (int b : buckets) {
-        if (x_taps > b) continue;
-        // sub-dword pixels: prefer a tap count whose span is whole dwords (dword loads + byte picks);
-        // spans that are not fall back to one load per sample and are only used for short filters
-        if (bpp % 4 != 0 && (b * bpp) % 4 != 0 && b > 3) continue;
-        return b;
+    if (bpp % 4 != 0) {  // sub-dword pixels: the rotated fetch takes the window as it is (see span_rotate)
+        for (int b : buckets)
+            if (x_taps <= b) { if (span_rotate(bpp, b)) return b; break; }
     }
+    // aligned fetch: room for moving the window start down to a 4-byte boundary, and a whole-dword window
+    const int room = bpp % 4 == 0 ? 0 : (bpp % 2 ? 3 : 1);
+    for (int b : buckets)
+        if (x_taps + room <= b && (b * bpp) % 4 == 0 && !span_rotate(bpp, b)) return b;
     return 0;
 }
-bool fused_x_bytespan(int x_taps_bucket, int pixel) {
+bool fused_x_bytespan(int x_taps_bucket, int pixel) {  // aligned fetch: the host must align the windows
     const int bpp = pixel_channels(pixel) * (pixel_is16(pixel) ? 2 : 1);
-    return bpp % 4 != 0 && (x_taps_bucket * bpp) % 4 == 0;
+    return bpp % 4 != 0 && !span_rotate(bpp, x_taps_bucket);
 }
 
 bool fused_multi_supported(int pixel, int per_lane, int step, int x_taps) {
