@@ -505,7 +505,15 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         // ... except the reference arithmetic with more than 5 taps, where two outputs per lane (fewer
         // conversions per output) wins by ~9 %
         const bool two_first = !fma && ax->host.taps > 5;
-        const int cand_s[] = {two_first ? 2 : 1, two_first ? 1 : 2, 4};
+        // sub-dword pixels (grey, rgb, greya, ...): several outputs per lane first — one lane then stores whole
+        // dwords and converts each source sample once for all its outputs; needs 4-byte aligned destination rows
+        const bool subdword = kBytes[pixel] % 4 != 0;
+        bool dst_dword_rows = true;
+        for (int i = 0; i < n && subdword; ++i)
+            if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % 4) dst_dword_rows = false;
+        const int cand_words[] = {two_first ? 2 : 1, two_first ? 1 : 2, 4};
+        const int cand_sub[] = {4, 2, 1};
+        const int (&cand_s)[3] = subdword ? cand_sub : cand_words;
         // cross-lane sharing variant (rgba8, exact 2x, 5 taps): fewest conversions per output and fully
         // coalesced loads, but measured 2-4 % SLOWER than the plain variant on cfg2 (the kernel is bound by
         // mixed read/write HBM traffic, not by the conversions it saves): opt-in only ("dpp" = 1)
@@ -514,7 +522,8 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             if (want_dpp && pl != 1) continue;
             if (!want_dpp) {
                 if (opt_per_lane > 0 && pl != opt_per_lane) continue;
-                if (opt_per_lane == 0 && pl == 4) continue;
+                if (opt_per_lane == 0 && pl == 4 && !subdword) continue;
+                if (subdword && pl > 1 && !dst_dword_rows) continue;
             }
             // two variants of the streaming kernel: rotating accumulators (default) or unrolled roles
             const bool prefer_rot = opt_rot != 2;

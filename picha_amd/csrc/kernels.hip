@@ -12,12 +12,30 @@ PICHA_DECL_SPAN(4) PICHA_DECL_SPAN(5) PICHA_DECL_SPAN(6) PICHA_DECL_SPAN(7)
 #undef PICHA_DECL_SPAN
 
 
+// defined in kernels_stream.hip, one translation unit per pixel format
+#define PICHA_DECL_STREAM(N)                                                                      \
+    bool stream_supported_pixel##N(int per_lane, int sx, int tx, int sy, int ty, int rot);        \
+    hipError_t launch_stream_pixel##N(const StreamParams &p, hipStream_t s, const char **name);
+PICHA_DECL_STREAM(0) PICHA_DECL_STREAM(1) PICHA_DECL_STREAM(2) PICHA_DECL_STREAM(3)
+PICHA_DECL_STREAM(4) PICHA_DECL_STREAM(5) PICHA_DECL_STREAM(6) PICHA_DECL_STREAM(7)
+#undef PICHA_DECL_STREAM
+
 bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot) {
-    return stream_supported(pixel, per_lane, sx, tx, sy, ty, rot);
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return stream_supported_pixel##N(per_lane, sx, tx, sy, ty, rot);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return false;
 }
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **name) {
     if (p.dpp) return pixel == 1 ? launch_stream_dpp(p, s, name) : hipErrorInvalidValue;
-    return launch_resize_stream(pixel, p, s, name);
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return launch_stream_pixel##N(p, s, name);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return hipErrorInvalidValue;
 }
 bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty) {
     return pixel == 1 && sx == 2 && tx == 5 && sy == 2 && ty == 5;
@@ -83,7 +101,7 @@ bool fused_multi_supported(int pixel, int per_lane, int step, int x_taps) {
 
 bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots, int per_lane) {
     if (pixel < 0 || pixel > 7) return false;
-    if (x_taps < 1 || fused_x_bucket(x_taps, pixel) == 0) return false;
+    if (x_taps < 1 || x_taps > 36) return false;  // x_taps is already a bucket (fused_x_bucket) or an exact multi-output tap count
     if (y_taps < 1 || y_taps > 32) return false;
     const int ch = pixel_channels(pixel);
     const size_t slot = (ch == 1 ? 4 : ch == 2 ? 8 : 16);

@@ -380,3 +380,70 @@ def test_resize_rgba_2x_cross_lane_sharing_kernel():
         assert ("dpp" in N.lib().picha_hip_last_kernel().decode() or sw < 16) and max_code_diff(got, exp) <= 1
         set_opt("numerics", 0)
     set_opt("dpp", 0)
+
+
+@pytest.mark.parametrize("pixel", ["grey", "rgb", "greya", "r16", "r16g16b16"])
+def test_resize_subdword_multi_output_streaming_kernel(pixel):
+    """Sub-dword pixels at integer scales: several outputs per lane, byte-rotated aligned dword loads, whole-dword
+    stores.  Ragged widths (partial last group), an unaligned source subView (descriptor re-based to a dword),
+    both numerics, row chunking; a destination whose rows are not 4-byte aligned must fall back, still bit-exact."""
+    rng = np.random.default_rng(300 + PIXELS.index(pixel))
+    bpp = N.PIXEL_BYTES[pixel]
+    streamed = 0
+    for scale, opts in ((2, {}), (2, {"filter": "cubic"}), (3, {}), (4, {})):
+        for (dw, dh) in [(320, 120), (131, 49), (9, 5), (517, 18)]:
+            sw, sh = dw * scale, dh * scale
+            img = rand_image(rng, sw, sh, pixel, pad=4 if dw == 131 else 0)
+            exp = oracle_resize(img, dw, dh, "cubic", 1.0 if opts else 0.70)
+            for chunks in (0, 3):
+                set_opt("row_chunks", chunks)
+                got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
+                name = N.lib().picha_hip_last_kernel().decode()
+                streamed += name.startswith("resize_stream<ch%d" % N.PIXEL_CHANNELS[pixel]) and ",P1," not in name
+                assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, chunks, name)
+            set_opt("row_chunks", 0)
+            set_opt("numerics", 1)
+            got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
+            assert max_code_diff(got, exp) <= 1, (pixel, sw, sh, "fma", N.lib().picha_hip_last_kernel())
+            set_opt("numerics", 0)
+    assert streamed >= 12, streamed   # the multi-output streaming kernel served (at least) the 2x cases
+    # source subView starting at an odd byte
+    big = rand_image(rng, 300, 120, pixel)
+    view = big.subView(3, 5, 256, 96)
+    exp = oracle_resize(picha_amd.Image(width=256, height=96, pixel=pixel, stride=big.stride, data=view.data.copy()), 128, 48)
+    got = picha_amd.resizeSync(view, {"width": 128, "height": 48})
+    assert max_code_diff(got, exp) == 0, N.lib().picha_hip_last_kernel()
+    # device-resident destination with an odd row stride: no whole-dword stores possible -> other kernel, same pixels
+    import torch
+    from picha_amd.device import DeviceBatch, resize_batch
+    src = DeviceBatch(2, 256, 96, pixel).fill_random(5)
+    odd = DeviceBatch(2, 128, 48, pixel, stride=128 * bpp + (2 if bpp % 2 == 0 else 1))
+    resize_batch(src, out=odd)
+    torch.cuda.synchronize()
+    name = N.lib().picha_hip_last_kernel().decode()
+    assert name.startswith("resize_span"), name
+    for i in range(2):
+        exp = oracle_resize(src.image_host(i), 128, 48)
+        assert np.array_equal(payload(odd.image_host(i)), payload(exp)), (pixel, i, name)
+
+
+def test_kernel_selection_for_the_baseline_workloads():
+    """The planner must keep serving BASELINE.json's workloads with the kernels DESIGN.md names (a silent fall back
+    to the two-pass kernels is a 10x performance regression that parity tests alone do not see)."""
+    rng = np.random.default_rng(7)
+    cases = [
+        ("rgba", 384, 216, 192, 108, {}, "resize_stream<ch4,u8,P1,SX2,TX5,SY2,TY5"),                     # cfg2
+        ("rgba", 384, 216, 192, 108, {"filter": "cubic"}, "resize_stream<ch4,u8,P2,SX2,TX7,SY2,TY7"),     # cfg2, 7 taps
+        ("grey", 3840, 216, 512, 51, {"filter": "lanczos"}, "resize_span<ch1,u8,P1,S1,TX36,TY32"),        # cfg3b (x: 7.5x)
+        ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_stream<ch4,u16,P1,SX4,TX15,SY4,TY15"),  # cfg5
+        ("rgb", 384, 216, 192, 108, {}, "resize_stream<ch3,u8,P4,SX2,TX5,SY2,TY5"),
+        ("grey", 384, 216, 192, 108, {}, "resize_stream<ch1,u8,P4,SX2,TX5,SY2,TY5"),
+        ("rgb", 300, 200, 130, 90, {}, "resize_span<ch3,u8,P1"),                                         # non-integer scale
+    ]
+    for pixel, sw, sh, dw, dh, opts, want in cases:
+        img = rand_image(rng, sw, sh, pixel)
+        got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
+        name = N.lib().picha_hip_last_kernel().decode()
+        assert name.startswith(want), (pixel, sw, sh, dw, dh, opts, name)
+        exp = oracle_resize(img, dw, dh, opts.get("filter", "cubic"), 1.0 if "filter" in opts else 0.70)
+        assert max_code_diff(got, exp) == 0, name
