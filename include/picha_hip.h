@@ -208,6 +208,10 @@ int picha_hip_convert_resize(const picha_image *src, const picha_image *dst, int
 int picha_hip_convert_resize_batch(int n, const picha_image *src, const picha_image *dst, int order,
                                    float r_factor, float g_factor, float b_factor, int filter,
                                    float filter_scale);
+/* through the batching dispatcher, like picha_hip_resize_async */
+int picha_hip_convert_resize_async(const picha_image *src, const picha_image *dst, int order, float r_factor,
+                                   float g_factor, float b_factor, int filter, float filter_scale,
+                                   picha_hip_done_fn done, void *user);
 
 /* ---- next to the path: Image helpers on device-resident images ----------------
  * Image.prototype.equalPixels / avgChannelDiff / copy (lib/image.js:57-96) without a D2H copy of the pixels.

@@ -9,6 +9,7 @@ from ._native import FILTERS, PIXELS, PichaError, lib  # noqa: F401
 from .api import (  # noqa: F401
     colorConvert,
     colorConvertSync,
+    convertResize,
     convertResizeSync,
     color_settings,
     drain,

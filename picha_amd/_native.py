@@ -71,6 +71,7 @@ SYMBOLS = [
     ("picha_hip_convert_resize_device", _i, [_i, _P, _P, _i, _f, _f, _f, _i, _f, _vp]),
     ("picha_hip_convert_resize", _i, [_P, _P, _i, _f, _f, _f, _i, _f]),
     ("picha_hip_convert_resize_batch", _i, [_i, _P, _P, _i, _f, _f, _f, _i, _f]),
+    ("picha_hip_convert_resize_async", _i, [_P, _P, _i, _f, _f, _f, _i, _f, _vp, _vp]),
     ("picha_hip_image_compare_device", _i, [_i, _P, _P, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64), _vp]),
     ("picha_hip_image_copy_device", _i, [_i, _P, _P, _vp]),
     ("picha_hip_malloc", _i, [ctypes.POINTER(_vp), _sz]),

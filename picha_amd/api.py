@@ -221,14 +221,7 @@ def colorConvert(image, opts, cb):
 
 
 # ---- next to the path: both operations in one device round trip ---------------
-def convertResizeSync(image, opts):
-    """resizeSync(colorConvertSync(image, opts), opts) — or, with opts.order == 'resizeFirst',
-    colorConvertSync(resizeSync(image, opts), opts) — as one call: the intermediate image stays in HBM.
-
-    opts carries both option sets: pixel (+ redWeight/greenWeight/blueWeight) and width, height (+ filter,
-    filterScale).  Results are bit-identical to the two reference calls in that order; errors are theirs.
-    """
-    expected = "expected: convertResizeSync(image, opts)"
+def _prepare_chain(image, opts, expected):
     src, mid, cs = _prepare_convert(image, opts, expected)
     width = _to_int32(_uint32(_get(opts, "width")))
     height = _to_int32(_uint32(_get(opts, "height")))
@@ -238,8 +231,29 @@ def convertResizeSync(image, opts):
     order = 1 if _get(opts, "order") == "resizeFirst" else 0
     dst = _new_image(width, height, mid.pixel)
     cdst = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index(dst.pixel))
+    return src, dst, cdst, order, cs, ftag, fscale
+
+
+def convertResizeSync(image, opts):
+    """resizeSync(colorConvertSync(image, opts), opts) — or, with opts.order == 'resizeFirst',
+    colorConvertSync(resizeSync(image, opts), opts) — as one call: the intermediate image stays in HBM.
+
+    opts carries both option sets: pixel (+ redWeight/greenWeight/blueWeight) and width, height (+ filter,
+    filterScale).  Results are bit-identical to the two reference calls in that order; errors are theirs.
+    """
+    src, dst, cdst, order, cs, ftag, fscale = _prepare_chain(image, opts, "expected: convertResizeSync(image, opts)")
     N.check(N.lib().picha_hip_convert_resize(ctypes.byref(src[0]), ctypes.byref(cdst), order, cs[0], cs[1], cs[2], ftag, fscale))
     return dst
+
+
+def convertResize(image, opts, cb):
+    """Async form of convertResizeSync, through the batching dispatcher (cb(None, image) from a library thread)."""
+    if not callable(cb):
+        raise PichaError("expected: convertResize(image, opts, cb)")
+    src, dst, cdst, order, cs, ftag, fscale = _prepare_chain(image, opts, "expected: convertResize(image, opts, cb)")
+    L = N.lib()
+    _submit_async(lambda done: L.picha_hip_convert_resize_async(ctypes.byref(src[0]), ctypes.byref(cdst), order, cs[0], cs[1],
+                                                                cs[2], ftag, fscale, done, None), src, dst, cb)
 
 
 # ---- helpers exposed for tests / tools ----------------------------------------------------------

@@ -1166,19 +1166,20 @@ int picha_hip_image_copy_device(int n, const picha_image *src, const picha_image
 
 // Validation of one host-pointer request (shared with the asynchronous dispatcher, dispatch.cpp).
 // Not part of the public header.
-int picha_hip_validate_host_op(int is_resize, const picha_image *src, const picha_image *dst, int filter,
-                               float filter_scale, int *device) {
+int picha_hip_validate_host_op(int kind, const picha_image *src, const picha_image *dst, int filter,
+                               float filter_scale, int *device) {  // kind: 0 colorConvert, 1 resize, 2 chained
     int rc = check_src(src);
     if (rc) return rc;
     rc = check_dst(dst);
     if (rc) return rc;
-    if (is_resize) {
+    if (kind != 0) {
         if (filter < 0 || filter >= PICHA_NUM_FILTERS) return fail(PICHA_ERR_INVALID_FILTER, "invalid filter mode");
         if (!(filter_scale > 0)) return fail(PICHA_ERR_INVALID_FILTER_WIDTH, "invalid filter width");
-        if (src->pixel != dst->pixel) return fail(PICHA_ERR_PIXEL_MISMATCH, "resize: source and destination pixel formats differ");
-    } else if (src->width != dst->width || src->height != dst->height) {
-        return fail(PICHA_ERR_PIXEL_MISMATCH, "colorConvert: source and destination sizes differ");
     }
+    if (kind == 1 && src->pixel != dst->pixel)
+        return fail(PICHA_ERR_PIXEL_MISMATCH, "resize: source and destination pixel formats differ");
+    if (kind == 0 && (src->width != dst->width || src->height != dst->height))
+        return fail(PICHA_ERR_PIXEL_MISMATCH, "colorConvert: source and destination sizes differ");
     return current_device(device);
 }
 

@@ -42,14 +42,16 @@ size_t image_span(const picha_image &im) {
 }
 
 struct Request {
-    bool is_resize;
+    int kind;   // 0 colorConvert, 1 resize, 2 both chained on the device (picha_hip_convert_resize_device)
+    int order;  // chained: picha_chain_order
     picha_image src, dst;
     int filter;
-    float p0, p1, p2;  // resize: p0 = filter scale; convert: r, g, b
+    float fscale;   // resize / chained
+    float r, g, b;  // colorConvert / chained
     picha_hip_done_fn done;
     void *user;
     bool compatible(const Request &o) const {
-        return is_resize == o.is_resize && filter == o.filter && p0 == o.p0 && p1 == o.p1 && p2 == o.p2;
+        return kind == o.kind && order == o.order && filter == o.filter && fscale == o.fscale && r == o.r && g == o.g && b == o.b;
     }
 };
 
@@ -170,8 +172,10 @@ private:
         int rc = PICHA_OK;
         if (e == hipSuccess) {
             const Request &r0 = s.reqs[0];
-            rc = r0.is_resize ? picha_hip_resize_device(n, dsrc.data(), ddst.data(), r0.filter, r0.p0, s.stream)
-                              : picha_hip_color_convert_device(n, dsrc.data(), ddst.data(), r0.p0, r0.p1, r0.p2, s.stream);
+            rc = r0.kind == 1   ? picha_hip_resize_device(n, dsrc.data(), ddst.data(), r0.filter, r0.fscale, s.stream)
+                 : r0.kind == 0 ? picha_hip_color_convert_device(n, dsrc.data(), ddst.data(), r0.r, r0.g, r0.b, s.stream)
+                                : picha_hip_convert_resize_device(n, dsrc.data(), ddst.data(), r0.order, r0.r, r0.g, r0.b,
+                                                                  r0.filter, r0.fscale, s.stream);
             if (rc != PICHA_OK) { s.status = rc; s.error = picha_hip_last_error(); }
         }
         if (e == hipSuccess && rc == PICHA_OK)
@@ -247,23 +251,25 @@ Dispatcher *dispatcher_for(int dev) {
 }
 
 // validation shared with the synchronous entry points lives in capi.cpp
-extern "C" int picha_hip_validate_host_op(int is_resize, const picha_image *src, const picha_image *dst, int filter,
+extern "C" int picha_hip_validate_host_op(int kind, const picha_image *src, const picha_image *dst, int filter,
                                           float filter_scale, int *device);
 
-int submit(bool is_resize, const picha_image *src, const picha_image *dst, int filter, float p0, float p1, float p2,
-           picha_hip_done_fn done, void *user) {
+int submit(int kind, int order, const picha_image *src, const picha_image *dst, int filter, float fscale, float r, float g,
+           float b, picha_hip_done_fn done, void *user) {
     int dev = 0;
-    int rc = picha_hip_validate_host_op(is_resize ? 1 : 0, src, dst, filter, p0, &dev);
+    int rc = picha_hip_validate_host_op(kind, src, dst, filter, fscale, &dev);
     if (rc != PICHA_OK) return rc;
-    Request r;
-    r.is_resize = is_resize;
-    r.src = *src;
-    r.dst = *dst;
-    r.filter = filter;
-    r.p0 = p0; r.p1 = p1; r.p2 = p2;
-    r.done = done;
-    r.user = user;
-    dispatcher_for(dev)->enqueue(r);
+    Request q;
+    q.kind = kind;
+    q.order = order;
+    q.src = *src;
+    q.dst = *dst;
+    q.filter = filter;
+    q.fscale = fscale;
+    q.r = r; q.g = g; q.b = b;
+    q.done = done;
+    q.user = user;
+    dispatcher_for(dev)->enqueue(q);
     return PICHA_OK;
 }
 
@@ -273,12 +279,18 @@ extern "C" {
 
 int picha_hip_resize_async(const picha_image *src, const picha_image *dst, int filter, float filter_scale,
                            picha_hip_done_fn done, void *user) {
-    return submit(true, src, dst, filter, filter_scale, 0.0f, 0.0f, done, user);
+    return submit(1, 0, src, dst, filter, filter_scale, 0.0f, 0.0f, 0.0f, done, user);
 }
 
 int picha_hip_color_convert_async(const picha_image *src, const picha_image *dst, float r, float g, float b,
                                   picha_hip_done_fn done, void *user) {
-    return submit(false, src, dst, 0, r, g, b, done, user);
+    return submit(0, 0, src, dst, 0, 0.0f, r, g, b, done, user);
+}
+
+int picha_hip_convert_resize_async(const picha_image *src, const picha_image *dst, int order, float r, float g, float b,
+                                   int filter, float filter_scale, picha_hip_done_fn done, void *user) {
+    if (order != PICHA_CONVERT_THEN_RESIZE && order != PICHA_RESIZE_THEN_CONVERT) return PICHA_ERR_ARGUMENT;
+    return submit(2, order, src, dst, filter, filter_scale, r, g, b, done, user);
 }
 
 int picha_hip_async_drain(void) {

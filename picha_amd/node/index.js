@@ -21,6 +21,7 @@ exports.colorConvertSync = function (img, opt) { return new Image(native.colorCo
 // outside the drop-in surface
 // resizeSync(colorConvertSync(img, opt), opt) — or the other order with opt.order === 'resizeFirst' — in one device
 // round trip: the intermediate image never leaves the GPU; same result as the two calls
+exports.convertResize = function (src, opt, cb) { native.convertResize(src, opt, wrap(cb)); };
 exports.convertResizeSync = function (img, opt) { return new Image(native.convertResizeSync(img, opt)); };
 exports.hipDeviceCount = native.hipDeviceCount;
 exports.hipLastKernel = native.hipLastKernel;

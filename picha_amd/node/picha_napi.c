@@ -301,8 +301,10 @@ static napi_value do_async(napi_env env, napi_callback_info info, int is_resize,
         return throw_msg(env, "could not create threadsafe function");
     }
     /* hand the request to the library's batching dispatcher (replaces uv_queue_work, src/resize.cc:362-364) */
-    int rc = c->is_resize ? picha_hip_resize_async(&c->src, &c->dst, c->filter, c->filter_scale, async_done, c)
-                          : picha_hip_color_convert_async(&c->src, &c->dst, c->cs[0], c->cs[1], c->cs[2], async_done, c);
+    int rc = c->is_resize == 2 ? picha_hip_convert_resize_async(&c->src, &c->dst, c->order, c->cs[0], c->cs[1], c->cs[2], c->filter,
+                                                                c->filter_scale, async_done, c)
+             : c->is_resize    ? picha_hip_resize_async(&c->src, &c->dst, c->filter, c->filter_scale, async_done, c)
+                               : picha_hip_color_convert_async(&c->src, &c->dst, c->cs[0], c->cs[1], c->cs[2], async_done, c);
     if (rc != PICHA_OK) { /* rejected synchronously, e.g. no device: throw like every other argument problem */
         char msg[512];
         const char *m = picha_hip_last_error();
@@ -325,6 +327,7 @@ static napi_value js_color_convert_sync(napi_env env, napi_callback_info info) {
 
 /* outside the drop-in surface: colorConvertSync + resizeSync in one device round trip (include/picha_hip.h, 8f row 2) */
 static napi_value js_convert_resize_sync(napi_env env, napi_callback_info info) { return do_sync(env, info, 2, "expected: convertResizeSync(image, opts)"); }
+static napi_value js_convert_resize(napi_env env, napi_callback_info info) { return do_async(env, info, 2, "expected: convertResize(image, opts, cb)"); }
 
 /* extras outside the drop-in surface */
 static napi_value js_device_count(napi_env env, napi_callback_info info) {
@@ -345,7 +348,7 @@ static napi_value init(napi_env env, napi_value exports) {
     struct { const char *name; napi_callback cb; } methods[] = {
         {"resize", js_resize}, {"resizeSync", js_resize_sync},
         {"colorConvert", js_color_convert}, {"colorConvertSync", js_color_convert_sync},
-        {"convertResizeSync", js_convert_resize_sync},
+        {"convertResizeSync", js_convert_resize_sync}, {"convertResize", js_convert_resize},
         {"hipDeviceCount", js_device_count}, {"hipLastKernel", js_last_kernel},
     };
     for (size_t i = 0; i < sizeof methods / sizeof methods[0]; ++i) {

@@ -145,6 +145,13 @@ if (!haveGpu) {
 		const d = picha.colorConvertSync(picha.resizeSync(image, { width: 32, height: 24 }), { pixel: 'rgba' });
 		assert(c.equalPixels(d));
 	});
+	test('convertResize (async, batching dispatcher) equals convertResizeSync', (done) => {
+		const o = { pixel: 'greya', width: 30, height: 20, filter: 'mitchel' };
+		picha.convertResize(image, o, (err, a) => {
+			if (err) return done(err);
+			try { assert(a.equalPixels(picha.convertResizeSync(image, o))); done(); } catch (e) { done(e); }
+		});
+	});
 	test('resize: every filter and a 16-bit format run', () => {
 		const big = new Image({ width: 64, height: 48, pixel: 'r16g16b16a16' });
 		for (let i = 0; i < big.data.length; ++i) big.data[i] = (i * 37 + 11) & 255;

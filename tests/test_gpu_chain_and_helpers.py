@@ -167,3 +167,29 @@ def test_device_image_copy_is_the_common_rectangle_payload_only():
         assert np.array_equal(got.data[: (30 - 1) * got.stride + 40], d_imgs[i].data[: (30 - 1) * got.stride + 40])
     with pytest.raises(N.PichaError, match="can't copy pixels between different pixel types"):
         src.copy_to(DeviceBatch(2, 20, 30, "rgb"))
+
+
+def test_convert_resize_async_batches_and_equals_sync():
+    import threading
+    rng = np.random.default_rng(21)
+    imgs = [rand_image(rng, 120, 80, "rgb") for _ in range(12)]
+    o = {"pixel": "grey", "width": 40, "height": 30, "filter": "lanczos"}
+    results, lock, done = {}, threading.Lock(), threading.Event()
+
+    def make_cb(i):
+        def cb(err, img):
+            with lock:
+                results[i] = (err, img)
+                if len(results) == len(imgs):
+                    done.set()
+        return cb
+    for i, im in enumerate(imgs):
+        picha.convertResize(im, o, make_cb(i))
+    picha.drain()
+    assert done.wait(30)
+    for i, im in enumerate(imgs):
+        err, got = results[i]
+        assert err is None
+        assert np.array_equal(payload(got), payload(picha.convertResizeSync(im, o)))
+    with pytest.raises(picha.PichaError, match="expected pixel mode"):
+        picha.convertResize(imgs[0], {"width": 4, "height": 4}, lambda e, i: None)
