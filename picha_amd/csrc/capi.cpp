@@ -763,6 +763,8 @@ int device_arena(int dev, size_t bytes, uint8_t **out) {
 
 enum class Op { Resize, Convert, Chain };
 
+extern "C" void picha_hip_staging_copy(void *dst, const void *src, size_t bytes);  // dispatch.cpp
+
 // Shared host-pointer driver: stage in, run the device entry point, stage out payload rows.
 int run_host(Op op, int n, const picha_image *src, const picha_image *dst, int filter, float fscale,
              float r, float g, float b, int order = 0) {
@@ -796,12 +798,20 @@ int run_host(Op op, int n, const picha_image *src, const picha_image *dst, int f
     rc = device_arena(dev, total + 256, &arena);
     if (rc) return rc;
     std::vector<picha_image> dsrc(src, src + n), ddst(dst, dst + n);
+    // stage in pieces: while the DMA engine moves one piece, the next one is being copied into the pinned mirror
+    // (by a few threads for large pieces, dispatch.cpp) — a 4K image is 33 MB, one memcpy of it takes longer than its H2D
+    constexpr size_t kPiece = 8u << 20;
+    hipError_t e0 = hipSuccess;
     for (int i = 0; i < n; ++i) {
         dsrc[i].data = arena + soff[i];
         ddst[i].data = arena + doff[i];
-        memcpy(pinned + soff[i], src[i].data, image_span(src[i]));
+        const size_t span = image_span(src[i]);
+        for (size_t off = 0; off < span && e0 == hipSuccess; off += kPiece) {
+            const size_t len = std::min(kPiece, span - off);
+            picha_hip_staging_copy(pinned + soff[i] + off, static_cast<const uint8_t *>(src[i].data) + off, len);
+            e0 = hipMemcpyAsync(arena + soff[i] + off, pinned + soff[i] + off, len, hipMemcpyHostToDevice, s);
+        }
     }
-    hipError_t e0 = hipMemcpyAsync(arena, pinned, dst_begin, hipMemcpyHostToDevice, s);
     if (e0 != hipSuccess) rc = fail(PICHA_ERR_HIP, "H2D failed: %s", hipGetErrorString(e0));
     if (rc == PICHA_OK)
         rc = (op == Op::Resize)    ? picha_hip_resize_device(n, dsrc.data(), ddst.data(), filter, fscale, s)
@@ -820,7 +830,7 @@ int run_host(Op op, int n, const picha_image *src, const picha_image *dst, int f
             const size_t rw = (size_t)dst[i].width * kBytes[dst[i].pixel];
             const uint8_t *from = pinned + doff[i];
             uint8_t *to = static_cast<uint8_t *>(dst[i].data);
-            if ((size_t)dst[i].stride == rw) memcpy(to, from, rw * dst[i].height);
+            if ((size_t)dst[i].stride == rw) picha_hip_staging_copy(to, from, rw * dst[i].height);
             else for (int y = 0; y < dst[i].height; ++y) memcpy(to + (size_t)y * dst[i].stride, from + (size_t)y * dst[i].stride, rw);
         }
     }
