@@ -160,3 +160,47 @@ def test_device_entry_point_is_graph_capturable():
     torch.cuda.synchronize()
     exp = oracle_resize(src.image_host(3), 640, 360, "cubic", 0.70)
     assert np.array_equal(dst.image_host(3).pixels(), exp.pixels())
+
+
+@pytest.mark.parametrize("pixel", ["rgb", "grey", "greya"])
+def test_full_size_subdword_2x_streaming_equals_span_kernel_and_oracle(pixel):
+    """4K -> 1080p in the sub-dword formats: the multi-output streaming kernel (byte-rotated loads, whole-dword
+    stores) and the LDS-ring span kernel must agree on every byte of a full batch (compared on the device with
+    picha_hip_image_compare_device) and match the oracle on sample images."""
+    n = 48
+    src = DeviceBatch(n, 3840, 2160, pixel).fill_random(11)
+    out = resize_batch(src, 1920, 1080)
+    torch.cuda.synchronize()
+    name = N.lib().picha_hip_last_kernel().decode()
+    assert name.startswith("resize_stream") and ",P4," in name, name
+    set_opt("path", 3)
+    ref = resize_batch(src, 1920, 1080)
+    torch.cuda.synchronize()
+    assert N.lib().picha_hip_last_kernel().decode().startswith("resize_span")
+    set_opt("path", 0)
+    assert all(out.equal_pixels(ref))
+    assert out.avg_channel_diff(ref) == [0.0] * n
+    for i in (0, n - 1):
+        exp = oracle_resize(src.image_host(i), 1920, 1080, "cubic", 0.70)
+        assert np.array_equal(out.image_host(i).pixels(), exp.pixels())
+    set_opt("numerics", 1)
+    fma = resize_batch(src, 1920, 1080)
+    torch.cuda.synchronize()
+    set_opt("numerics", 0)
+    d = fma.avg_channel_diff(out)
+    assert max(d) < 0.25 and not all(fma.equal_pixels(out)), d   # a few samples differ by one code value, no more
+
+
+def test_cfg3_full_size_chained_call_equals_the_two_calls():
+    from picha_amd.device import convert_resize_batch
+    n = 64
+    src = DeviceBatch(n, 3840, 2160, "rgb").fill_random(3)
+    two = resize_batch(color_convert_batch(src, "grey"), 512, 512, filter="lanczos")
+    one = convert_resize_batch(src, "grey", 512, 512, filter="lanczos")
+    torch.cuda.synchronize()
+    assert all(one.equal_pixels(two))
+    other = convert_resize_batch(src, "grey", 512, 512, filter="lanczos", order=1)   # resize in rgb first, then convert
+    ref = color_convert_batch(resize_batch(src, 512, 512, filter="lanczos"), "grey")
+    torch.cuda.synchronize()
+    assert all(other.equal_pixels(ref))
+    assert not all(other.equal_pixels(one))   # the two orders are different operations
