@@ -55,7 +55,7 @@ def cpu_baseline(name, budget_images=96):
         threads = min(threads, len(os.sched_getaffinity(0)))
     except AttributeError:
         pass
-    bpp = {"rgba": 4, "grey": 1, "r16g16b16a16": 8, "rgb": 3}[pixel]
+    bpp = {"rgba": 4, "grey": 1, "r16g16b16a16": 8, "rgb": 3, "greya": 2, "r16": 2, "r16g16": 4, "r16g16b16": 6}[pixel]
     n_img = max(threads, min(budget_images, threads * 4))
     if sw * sh * bpp > 100e6:
         n_img = threads
@@ -82,7 +82,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg2_4k_rgba_to_1080p_cubic", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="cfg2_4k_rgba_to_1080p_cubic", choices=sorted(WORKLOADS) + ["custom"])
+    ap.add_argument("--shape", default="", help="with --workload custom: n:pixel:src_w:src_h:dst_w:dst_h[:filter[:filterScale]]")
     ap.add_argument("--images", type=int, default=0, help="override images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--numerics", choices=["fma", "exact"], default="exact",
@@ -126,6 +127,14 @@ def main():
         set_opt(k, v)
     numerics = "fma" if N.lib().picha_hip_get_option(b"numerics") == 1 else "exact"
 
+    if args.workload == "custom":
+        f = args.shape.split(":")
+        o = {}
+        if len(f) > 6 and f[6]:
+            o["filter"] = f[6]
+        if len(f) > 7:
+            o["filterScale"] = float(f[7])
+        WORKLOADS["custom"] = (int(f[0]), int(f[2]), int(f[3]), f[1], int(f[4]), int(f[5]), o)
     n, sw, sh, pixel, dw, dh, opts = WORKLOADS[args.workload]
     if args.images:
         n = args.images
