@@ -126,6 +126,8 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "row_chunks" 0 = auto, else number of row chunks per image for the fused kernels
  *   "stream_rot" 0 = auto, 1 / 2 = force the rotating-accumulator / unrolled variant of the streaming kernel
  *   "dpp"        1 = use the cross-lane pixel-sharing streaming kernel where it applies (rgba, 2x, 5 taps)
+ *   "xcd_remap"  streaming kernel: 0 = auto, 1 = always / 2 = never permute workgroup ids so that each XCD works
+ *                through a contiguous range of (column strip, row chunk, image) and neighbours share its L2
  *   "chain_window_mb"  size of the intermediate buffer of picha_hip_convert_resize* in MB (default 4096)
  * Returns PICHA_ERR_ARGUMENT for an unknown key.
  */

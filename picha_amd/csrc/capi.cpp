@@ -68,6 +68,7 @@ long g_opt_numerics = [] {
 // were measured SLOWER (r01, profiles/r01_chain_window.txt: 96 MB 2.91 ms vs unsliced 2.49 ms for cfg3 — the short
 // launches do not fill the chip), so the window only bounds memory.
 long g_opt_chain_window_mb = 4096;
+long g_opt_xcd_remap = 0;   // streaming kernel, XCD-contiguous workgroup order: 0 auto (on for >= 2 outputs per lane), 1 on, 2 off
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 long g_opt_stream_rot = 0;  // 0 auto, 1 force the rotating-accumulator streaming variant, 2 force the unrolled one
 long g_opt_dpp = 0;         // 0 auto, 1 prefer / 2 forbid the cross-lane pixel-sharing streaming kernel
@@ -457,12 +458,13 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (rc) return rc;
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
-    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp;
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
         opt_rot = g_opt_stream_rot;
         opt_dpp = g_opt_dpp;
+        opt_xcd = g_opt_xcd_remap;
     }
     const int fma = opt_numerics == 1 ? 1 : 0;
     const int is16 = pixel >= PICHA_R16;
@@ -504,7 +506,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         // both numerics, and has the smallest code and register footprint
         // ... except the reference arithmetic with more than 5 taps, where two outputs per lane (fewer
         // conversions per output) wins by ~9 %
-        const bool two_first = !fma && ax->host.taps > 5;
+        // ... and, since the workgroup order became XCD-contiguous (xcd_remap: -5 % for two outputs per lane, nothing
+        // for one), the reference arithmetic is fastest with two outputs per lane at 5 taps too (cfg2: 2.39 vs 2.48 ms);
+        // the fma flavour is equally fast either way (profiles/r01_ab_xcd_remap.txt)
+        const bool two_first = !fma;
         // sub-dword pixels (grey, rgb, greya, ...): several outputs per lane first — one lane then stores whole
         // dwords and converts each source sample once for all its outputs; needs 4-byte aligned destination rows
         const bool subdword = kBytes[pixel] % 4 != 0;
@@ -573,6 +578,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             p.y_step_weight = cy->step_weight; p.y_step = sy; p.y_taps = ay->host.taps; p.y_base = cy->base;
             p.rot = rot;
             p.dpp = want_dpp ? 1 : 0;
+            p.xcd_remap = opt_xcd == 1 || (opt_xcd == 0 && pl >= 2) ? 1 : 0;
             const long long col_waves = (cx->groups + 63) / 64;
             long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
             chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
@@ -955,6 +961,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "per_lane") == 0) { g_opt_per_lane = value; return PICHA_OK; }
     if (strcmp(key, "stream_rot") == 0) { g_opt_stream_rot = value; return PICHA_OK; }
     if (strcmp(key, "dpp") == 0) { g_opt_dpp = value; return PICHA_OK; }
+    if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
     if (strcmp(key, "chain_window_mb") == 0) { g_opt_chain_window_mb = value; return PICHA_OK; }
     return fail(PICHA_ERR_ARGUMENT, "unknown option %s", key);
 }
@@ -967,6 +974,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "per_lane") == 0) return g_opt_per_lane;
     if (strcmp(key, "stream_rot") == 0) return g_opt_stream_rot;
     if (strcmp(key, "dpp") == 0) return g_opt_dpp;
+    if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
     if (strcmp(key, "chain_window_mb") == 0) return g_opt_chain_window_mb;
     return -1;
 }

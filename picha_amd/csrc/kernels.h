@@ -120,6 +120,7 @@ struct StreamParams {
                                  // last dword of a record: int flag, 1 = weights identical to the previous record
     int y_step, y_taps, y_base;
     int rot;  // 1: row-granular variant with rotating accumulators; 0: step-granular, fully unrolled roles
+    int xcd_remap;  // 1: permute workgroup ids so each XCD gets a contiguous range of (strip, chunk, image)
     int dpp;  // 1: cross-lane pixel-sharing variant (x tables: per_lane 1, uniform base step*x + L0, L0 == -1)
     int rows_per_chunk, n_chunks;
 };

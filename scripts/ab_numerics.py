@@ -16,13 +16,14 @@ if len(sys.argv) > 1:
 res = {}
 for rnd in range(4):
     for v in variants:
+        for k in ('numerics', 'per_lane', 'path', 'row_chunks', 'stream_rot', 'dpp', 'xcd_remap'): opt(k, 0)  # no state carried between variants
         for k, x in v.items(): opt(k, x)
         plan.run(); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         for _ in range(10): plan.run()
         e1.record(); torch.cuda.synchronize()
-        name = N.lib().picha_hip_last_kernel().decode() + ' ' + json.dumps({k: x for k, x in v.items() if k not in ('numerics', 'per_lane', 'path')})
+        name = N.lib().picha_hip_last_kernel().decode() + ' ' + json.dumps({k: x for k, x in v.items() if k not in ('numerics', 'path')})
         res.setdefault(name, []).append(e0.elapsed_time(e1) / 10)
 for k, v in res.items():
     print('%-62s %s  min %.3f' % (k, ' '.join('%.3f' % x for x in v), min(v)))

@@ -433,7 +433,7 @@ def test_kernel_selection_for_the_baseline_workloads():
     to the two-pass kernels is a 10x performance regression that parity tests alone do not see)."""
     rng = np.random.default_rng(7)
     cases = [
-        ("rgba", 384, 216, 192, 108, {}, "resize_stream<ch4,u8,P1,SX2,TX5,SY2,TY5"),                     # cfg2
+        ("rgba", 384, 216, 192, 108, {}, "resize_stream<ch4,u8,P2,SX2,TX5,SY2,TY5"),                     # cfg2
         ("rgba", 384, 216, 192, 108, {"filter": "cubic"}, "resize_stream<ch4,u8,P2,SX2,TX7,SY2,TY7"),     # cfg2, 7 taps
         ("grey", 3840, 216, 512, 51, {"filter": "lanczos"}, "resize_span<ch1,u8,P1,S1,TX36,TY32"),        # cfg3b (x: 7.5x)
         ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_stream<ch4,u16,P1,SX4,TX15,SY4,TY15"),  # cfg5
