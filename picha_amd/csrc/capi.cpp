@@ -636,6 +636,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         p.y_info = ay->y_info; p.y_weight = ay->y_weight; p.y_slot = ay->y_slot;
         p.y_taps = ay->host.taps; p.y_pad = ay->y_pad;
         p.ring_slots = ring;
+        p.xcd_remap = opt_xcd == 1 ? 1 : 0;
         // row chunks: enough waves to fill 256 CUs several times over, chunks not too short
         const long long col_waves = (xt->groups + 63) / 64;
         long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);

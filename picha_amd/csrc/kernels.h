@@ -69,6 +69,7 @@ struct FusedParams {
     int y_taps, y_pad;
     int ring_slots;
     int rows_per_chunk, n_chunks;
+    int xcd_remap;  // 1: XCD-contiguous workgroup order (see kernels_impl.inc, xcd_contiguous_block)
 };
 // True if a fused instantiation exists for this format / tap counts and its LDS ring fits.
 bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots, int per_lane);
