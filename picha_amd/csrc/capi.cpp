@@ -507,9 +507,9 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         // ... except the reference arithmetic with more than 5 taps, where two outputs per lane (fewer
         // conversions per output) wins by ~9 %
         // ... and, since the workgroup order became XCD-contiguous (xcd_remap: -5 % for two outputs per lane, nothing
-        // for one), the reference arithmetic is fastest with two outputs per lane at 5 taps too (cfg2: 2.39 vs 2.48 ms);
-        // the fma flavour is equally fast either way (profiles/r01_ab_xcd_remap.txt)
-        const bool two_first = !fma;
+        // for one), two outputs per lane are the fastest layout for both numerics (cfg2 on one box: reference arithmetic
+        // 2.24 vs 2.37 ms, fma 2.17 vs 2.23 ms; profiles/r01_ab_xcd_remap.txt)
+        const bool two_first = true;
         // sub-dword pixels (grey, rgb, greya, ...): several outputs per lane first — one lane then stores whole
         // dwords and converts each source sample once for all its outputs; needs 4-byte aligned destination rows
         const bool subdword = kBytes[pixel] % 4 != 0;
