@@ -531,7 +531,9 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 if (subdword && pl > 1 && !dst_dword_rows) continue;
             }
             // two variants of the streaming kernel: rotating accumulators (default) or unrolled roles
-            const bool prefer_rot = opt_rot != 2;
+            // measured with the XCD order and short row chunks (profiles/r01_ab_row_chunks.txt): for two outputs per
+            // lane and <= 5 taps the unrolled variant is 1-2 % ahead of the rotating one; otherwise the rotating one
+            const bool prefer_rot = opt_rot == 1 || (opt_rot == 0 && !(pl == 2 && ax->host.taps <= 5 && !subdword));
             int rot = want_dpp ? 1 : -1;
             for (int attempt = 0; attempt < 2 && rot < 0; ++attempt) {
                 const int r = (attempt == 0) == prefer_rot ? 1 : 0;
@@ -580,7 +582,12 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             p.dpp = want_dpp ? 1 : 0;
             p.xcd_remap = opt_xcd == 1 || (opt_xcd == 0 && pl >= 2) ? 1 : 0;
             const long long col_waves = (cx->groups + 63) / 64;
+            // row chunks: at least ~32 K waves per launch, chunks of >= 16 output rows.  Every chunk re-reads and
+            // re-filters TY - SY halo rows.  The reference arithmetic is VALU-bound and wants few, long chunks; the fma
+            // flavour is memory-bound and gains 3 % from ~40-row chunks when the halo is short (in XCD-contiguous order
+            // the chunks in flight on an XCD then cover a compact piece of the image): profiles/r01_ab_row_chunks.txt
             long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
+            if (opt_chunks <= 0 && fma && ay->host.taps - sy <= 5) chunks = std::max<long long>(chunks, (d0.height + 39) / 40);
             chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
             p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
             p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;

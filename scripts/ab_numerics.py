@@ -6,8 +6,9 @@ from picha_amd import _native as N
 from picha_amd.device import DeviceBatch, ResizePlan
 def opt(k, v): N.check(N.lib().picha_hip_set_option(k.encode(), v))
 torch.cuda.set_device(0)
-src = DeviceBatch(256, 3840, 2160, 'rgba').fill_random(1)
-dst = DeviceBatch(256, 1920, 1080, 'rgba')
+shape = sys.argv[3].split(':') if len(sys.argv) > 3 else ['256', 'rgba', '3840', '2160', '1920', '1080']   # n:pixel:sw:sh:dw:dh
+src = DeviceBatch(int(shape[0]), int(shape[2]), int(shape[3]), shape[1]).fill_random(1)
+dst = DeviceBatch(int(shape[0]), int(shape[4]), int(shape[5]), shape[1])
 plan_opts = json.loads(sys.argv[2]) if len(sys.argv) > 2 else {}
 plan = ResizePlan(src, dst, filter=plan_opts.get('filter'), filter_scale=plan_opts.get('filterScale'))
 variants = [dict(numerics=n, per_lane=p, path=pa) for n in (0, 1) for (p, pa) in ((2, 2), (1, 2), (4, 2), (2, 3))]
