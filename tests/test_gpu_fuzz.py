@@ -17,7 +17,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap"):
         set_opt(k, 0)
 
 
@@ -40,14 +40,18 @@ def _sizes(rng):
     return int(rng.integers(1, 200)), int(rng.integers(1, 150)), int(rng.integers(1, 200)), int(rng.integers(1, 150))
 
 
-@pytest.mark.parametrize("seed", range(6))
+import os
+N_SEEDS = int(os.environ.get("PICHA_FUZZ_SEEDS", "6"))   # a longer one-off sweep: PICHA_FUZZ_SEEDS=100
+
+
+@pytest.mark.parametrize("seed", range(N_SEEDS))
 def test_random_resizes_match_oracle(seed):
     rng = np.random.default_rng(1000 + seed)
     checked = 0
     for _ in range(70):
         sw, sh, dw, dh = _sizes(rng)
         pixel = PIXELS[int(rng.integers(0, 8))]
-        img = rand_image(rng, sw + int(rng.integers(0, 4)), sh + int(rng.integers(0, 3)), pixel, pad=int(rng.choice([0, 0, 4, 8])),
+        img = rand_image(rng, sw + int(rng.integers(0, 4)), sh + int(rng.integers(0, 3)), pixel, pad=int(rng.choice([0, 0, 4, 8, 1, 2, 3])),
                          edge_values=bool(rng.integers(0, 4) == 0))
         if img.width > sw or img.height > sh:  # exercise subViews (offset + parent stride; may be unaligned)
             img = img.subView(img.width - sw, img.height - sh, sw, sh)
@@ -74,6 +78,7 @@ def test_random_resizes_match_oracle(seed):
         set_opt("per_lane", int(rng.choice([0, 0, 1, 2, 4])))
         set_opt("row_chunks", int(rng.choice([0, 0, 1, 2, 7])))
         set_opt("stream_rot", int(rng.choice([0, 1, 2])))
+        set_opt("xcd_remap", int(rng.choice([0, 1, 2])))
         try:
             got = picha_amd.resizeSync(img, opts)
         except picha_amd.PichaError as e:
