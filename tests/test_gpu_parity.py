@@ -448,3 +448,44 @@ def test_kernel_selection_for_the_baseline_workloads():
         assert name.startswith(want), (pixel, sw, sh, dw, dh, opts, name)
         exp = oracle_resize(img, dw, dh, opts.get("filter", "cubic"), 1.0 if "filter" in opts else 0.70)
         assert max_code_diff(got, exp) == 0, name
+
+
+def test_sync_entry_points_are_thread_safe():
+    """The reference runs one image per libuv worker (4 by default); the C ABI promises the same freedom: concurrent
+    calls from several host threads (per-thread streams and staging, shared table caches and scratch) must each
+    return the right pixels.  Mixed operations, geometries that need the two-pass scratch and pointer tables."""
+    import threading
+    rng = np.random.default_rng(77)
+    jobs = []
+    for k in range(48):
+        pixel = PIXELS[k % 8]
+        sw, sh = int(rng.integers(20, 200)), int(rng.integers(20, 120))
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 4])))
+        kind = k % 3
+        if kind == 0:
+            dw, dh = max(1, sw // 2), max(1, sh // 2)
+            jobs.append((img, "resize", {"width": dw, "height": dh}, oracle_resize(img, dw, dh)))
+        elif kind == 1:
+            dw, dh = int(rng.integers(5, 90)), int(rng.integers(5, 70))
+            jobs.append((img, "resize", {"width": dw, "height": dh, "filter": "lanczos"}, oracle_resize(img, dw, dh, "lanczos", 1.0)))
+        else:
+            to = PIXELS[(k + 3) % 8]
+            jobs.append((img, "convert", {"pixel": to}, oracle_convert(img, to)))
+    errors = []
+
+    def worker(tid):
+        try:
+            for rep in range(6):
+                for j in range(tid, len(jobs), 8):
+                    img, op, opts, want = jobs[j]
+                    got = picha_amd.resizeSync(img, opts) if op == "resize" else picha_amd.colorConvertSync(img, opts)
+                    if not np.array_equal(payload(got), payload(want)):
+                        errors.append((tid, j, op, opts))
+        except Exception as e:  # noqa: BLE001
+            errors.append((tid, repr(e)))
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors[:5]
