@@ -580,7 +580,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             p.y_step_weight = cy->step_weight; p.y_step = sy; p.y_taps = ay->host.taps; p.y_base = cy->base;
             p.rot = rot;
             p.dpp = want_dpp ? 1 : 0;
-            p.xcd_remap = opt_xcd == 1 || (opt_xcd == 0 && pl >= 2) ? 1 : 0;
+            p.xcd_remap = opt_xcd == 1 || (opt_xcd == 0 && (pl >= 2 || want_dpp)) ? 1 : 0;
             const long long col_waves = (cx->groups + 63) / 64;
             // row chunks: at least ~32 K waves per launch, chunks of >= 16 output rows.  Every chunk re-reads and
             // re-filters TY - SY halo rows.  The reference arithmetic is VALU-bound and wants few, long chunks; the fma
