@@ -18,7 +18,7 @@ print('%-16s %-14s %-58s %8s %8s %6s' % ('case', 'pixel', 'kernel', 'ms', 'GB/s'
 for name, sw, sh, dw, dh, o in cases:
     if only and name not in only:
         continue
-    for pixel in ['rgba', 'rgb', 'grey', 'greya', 'r16g16b16a16', 'r16']:
+    for pixel in (sys.argv[5].split(',') if len(sys.argv) > 5 else ['rgba', 'rgb', 'grey', 'greya', 'r16g16b16a16', 'r16']):
         src = DeviceBatch(n, sw, sh, pixel).fill_random(3)
         dst = DeviceBatch(n, dw, dh, pixel)
         plan = ResizePlan(src, dst, filter=o.get('filter'), filter_scale=o.get('filterScale'))
