@@ -390,12 +390,12 @@ def test_resize_subdword_multi_output_streaming_kernel(pixel):
     rng = np.random.default_rng(300 + PIXELS.index(pixel))
     bpp = N.PIXEL_BYTES[pixel]
     streamed = 0
-    for scale, opts in ((2, {}), (2, {"filter": "cubic"}), (3, {}), (4, {})):
+    for scale, opts in ((2, {}), (2, {"filter": "cubic"}), (3, {}), (4, {}), (2, {"filter": "triangle"}), (4, {"filter": "mitchel"})):
         for (dw, dh) in [(320, 120), (131, 49), (9, 5), (517, 18)]:
             sw, sh = dw * scale, dh * scale
             # padded strides: +4 keeps rows dword-congruent, +1 makes the byte phase of a lane's window change every row
             img = rand_image(rng, sw, sh, pixel, pad={131: 4, 517: 1}.get(dw, 0))
-            exp = oracle_resize(img, dw, dh, "cubic", 1.0 if opts else 0.70)
+            exp = oracle_resize(img, dw, dh, opts.get("filter", "cubic"), 1.0 if opts else 0.70)
             for chunks in (0, 3):
                 set_opt("row_chunks", chunks)
                 got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
