@@ -501,22 +501,16 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (fused_ok && opt_path != 1 && opt_path != 3) {
         const int sx = std::max(1, (int)std::lround((double)s0.width / d0.width));
         const int sy = std::max(1, (int)std::lround((double)s0.height / d0.height));
-        // measured on MI355X (interleaved A/B on cfg2, profiles/): all lane layouts land within ~4 %; one
-        // output per lane with the rotating-accumulator variant is the best or within noise of the best for
-        // both numerics, and has the smallest code and register footprint
-        // ... except the reference arithmetic with more than 5 taps, where two outputs per lane (fewer
-        // conversions per output) wins by ~9 %
-        // ... and, since the workgroup order became XCD-contiguous (xcd_remap: -5 % for two outputs per lane, nothing
-        // for one), two outputs per lane are the fastest layout for both numerics (cfg2 on one box: reference arithmetic
-        // 2.24 vs 2.37 ms, fma 2.17 vs 2.23 ms; profiles/r01_ab_xcd_remap.txt)
-        const bool two_first = true;
+        // lane layouts, measured on cfg2 with the XCD-contiguous workgroup order (profiles/r01_ab_xcd_remap.txt): two
+        // outputs per lane are the fastest for both numerics (reference arithmetic 2.24 vs 2.37 ms for one output per
+        // lane, fma 2.17 vs 2.23 ms); four outputs cost too many registers for dword-sized pixels
         // sub-dword pixels (grey, rgb, greya, ...): several outputs per lane first — one lane then stores whole
         // dwords and converts each source sample once for all its outputs; needs 4-byte aligned destination rows
         const bool subdword = kBytes[pixel] % 4 != 0;
         bool dst_dword_rows = true;
         for (int i = 0; i < n && subdword; ++i)
             if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % 4) dst_dword_rows = false;
-        const int cand_words[] = {two_first ? 2 : 1, two_first ? 1 : 2, 4};
+        const int cand_words[] = {2, 1, 4};
         const int cand_sub[] = {4, 2, 1};
         const int (&cand_s)[3] = subdword ? cand_sub : cand_words;
         // cross-lane sharing variant (rgba8, exact 2x, 5 taps): fewest conversions per output and fully
