@@ -128,6 +128,10 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "dpp"        1 = use the cross-lane pixel-sharing streaming kernel where it applies (rgba, 2x, 5 taps)
  *   "xcd_remap"  streaming kernel: 0 = auto, 1 = always / 2 = never permute workgroup ids so that each XCD works
  *                through a contiguous range of (column strip, row chunk, image) and neighbours share its L2
+ *   "async_devices"  asynchronous entry points: 0 = queue on the caller's current device (default); N > 0 = deal
+ *                requests round-robin to the first min(N, visible) devices, one dispatcher each — a single host
+ *                process then drives every GPU of a node with independent images (environment:
+ *                PICHA_HIP_ASYNC_DEVICES)
  *   "chain_window_mb"  size of the intermediate buffer of picha_hip_convert_resize* in MB (default 4096)
  * Returns PICHA_ERR_ARGUMENT for an unknown key.
  */

@@ -69,6 +69,11 @@ long g_opt_numerics = [] {
 // launches do not fill the chip), so the window only bounds memory.
 long g_opt_chain_window_mb = 4096;
 long g_opt_xcd_remap = 0;   // streaming kernel, XCD-contiguous workgroup order: 0 auto (on for >= 2 outputs per lane), 1 on, 2 off
+// async dispatcher: 0 = the caller's current device, N = round-robin over the first N devices (PICHA_HIP_ASYNC_DEVICES)
+long g_opt_async_devices = [] {
+    const char *e = getenv("PICHA_HIP_ASYNC_DEVICES");
+    return e ? std::max(0L, atol(e)) : 0L;
+}();
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 long g_opt_stream_rot = 0;  // 0 auto, 1 force the rotating-accumulator streaming variant, 2 force the unrolled one
 long g_opt_dpp = 0;         // 0 auto, 1 prefer / 2 forbid the cross-lane pixel-sharing streaming kernel
@@ -964,6 +969,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "stream_rot") == 0) { g_opt_stream_rot = value; return PICHA_OK; }
     if (strcmp(key, "dpp") == 0) { g_opt_dpp = value; return PICHA_OK; }
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
+    if (strcmp(key, "async_devices") == 0) { g_opt_async_devices = value; return PICHA_OK; }
     if (strcmp(key, "chain_window_mb") == 0) { g_opt_chain_window_mb = value; return PICHA_OK; }
     return fail(PICHA_ERR_ARGUMENT, "unknown option %s", key);
 }
@@ -977,6 +983,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "stream_rot") == 0) return g_opt_stream_rot;
     if (strcmp(key, "dpp") == 0) return g_opt_dpp;
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
+    if (strcmp(key, "async_devices") == 0) return g_opt_async_devices;
     if (strcmp(key, "chain_window_mb") == 0) return g_opt_chain_window_mb;
     return -1;
 }

@@ -327,6 +327,16 @@ int submit(int kind, int order, const picha_image *src, const picha_image *dst, 
     int dev = 0;
     int rc = picha_hip_validate_host_op(kind, src, dst, filter, fscale, &dev);
     if (rc != PICHA_OK) return rc;
+    // "async_devices" = N > 0: requests are dealt round-robin to devices 0 .. min(N, visible) - 1, each with its own
+    // dispatcher (stager, completer, streams, staging): one host process feeds every GPU of the node with independent
+    // images, no exchange between devices.  Default (0): the caller's current device only.
+    const long want = picha_hip_get_option("async_devices");
+    if (want > 0) {
+        static std::atomic<unsigned> next{0};
+        int ndev = 1;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
+        dev = (int)(next.fetch_add(1) % (unsigned)std::min<long>(want, ndev));
+    }
     Request q;
     q.kind = kind;
     q.order = order;

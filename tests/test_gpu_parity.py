@@ -489,3 +489,22 @@ def test_sync_entry_points_are_thread_safe():
     for t in threads:
         t.join()
     assert not errors, errors[:5]
+
+
+def test_async_round_robin_over_devices_option():
+    """async_devices = N deals requests to the first min(N, visible) devices; with one visible GPU everything lands on
+    device 0 and results are unchanged (the multi-GPU spread itself needs a multi-GPU host)."""
+    import threading
+    rng = np.random.default_rng(5)
+    imgs = [rand_image(rng, 96, 64, "rgba") for _ in range(10)]
+    set_opt("async_devices", 4)
+    try:
+        out, lock = {}, threading.Lock()
+        for i, im in enumerate(imgs):
+            picha_amd.resize(im, {"width": 48, "height": 32}, (lambda k: (lambda e, r: out.__setitem__(k, (e, r))))(i))
+        picha_amd.drain()
+    finally:
+        set_opt("async_devices", 0)
+    for i, im in enumerate(imgs):
+        err, got = out[i]
+        assert err is None and max_code_diff(got, oracle_resize(im, 48, 32)) == 0
