@@ -1,0 +1,48 @@
+"""bench.py's one-line JSON contract (the driver parses it): keys, types and the roofline / cpu_baseline objects."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(*args):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    return json.loads(lines[0])
+
+
+def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
+    d = _run("--images", "8", "--steps", "3", "--warmup", "1", "--prewarm-ms", "5")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["higher_is_better"] is True
+    assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "Mpix/s"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["parity_max_code_diff_vs_oracle_image0"] == 0          # bit-exact default flavour
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["algorithmic_bytes_per_launch"] == 8 * (3840 * 2160 * 4 + 1920 * 1080 * 4)
+    assert r["traffic"] is None or r["traffic"] >= r["algorithmic_bytes_per_launch"]
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["unit"] == "Mpix/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    assert d["other_numerics"]["numerics"] == "fma" and d["other_numerics"]["parity_max_code_diff_vs_oracle_image0"] <= 1
+    # value = source pixels of all timed steps / elapsed
+    assert abs(d["value"] - 8 * 3840 * 2160 * 3 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 0.01
+
+
+def test_bench_other_workloads_run():
+    for w in ("cfg3a_4k_rgb_to_grey", "cfg3_4k_rgb_to_grey_to_512_lanczos_chained"):
+        d = _run("--workload", w, "--images", "4", "--steps", "2", "--warmup", "1", "--prewarm-ms", "0", "--no-cpu-baseline")
+        assert d["value"] > 0 and d["roofline"]["frac"] > 0
+    d = _run("--workload", "custom", "--shape", "4:rgb:640:480:320:240", "--steps", "2", "--warmup", "1", "--prewarm-ms", "0",
+             "--no-cpu-baseline")
+    assert "resize_stream<ch3" in d["config"]["kernel"]
