@@ -235,6 +235,13 @@ int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, std::sh
         }
     }
 
+    // y_info.x = the first source row needed by this output row OR ANY LATER ONE: a row chunk starts resampling there.
+    // left[] itself is not monotonic — trimming exact-zero end taps (src/resize.cc:31-34) can move one row's left past
+    // its successor's (catmulrom / mitchel / cubic upscales, whose kernels are exactly 0 at integer offsets); a chunk
+    // that started at its first row's own left would then never resample a row the next output needs.  need[] is
+    // taken before trimming and is monotonic.
+    for (int i = dst - 2; i >= 0; --i) y_info[i].x = std::min(y_info[i].x, y_info[i + 1].x);
+
     struct Part { const void *src; size_t bytes; void **dst; };
     Part parts[] = {
         {t.left.data(), sizeof(int32_t) * dst, (void **)&ax->left},

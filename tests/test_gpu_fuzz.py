@@ -89,7 +89,8 @@ def test_random_resizes_match_oracle(seed):
             got = picha_amd.resizeSync(img, opts)
         d = max_code_diff(got, exp)
         name = N.lib().picha_hip_last_kernel().decode()
-        assert d <= (1 if numerics and path != 1 else 0), (seed, sw, sh, dw, dh, pixel, opts, path, numerics, name, d)
+        assert d <= (1 if numerics and path != 1 else 0), "seed %d: %dx%d -> %dx%d %s opts %r path %d numerics %d kernel %s stride %d offset %d: diff %d" % (
+            seed, sw, sh, dw, dh, pixel, opts, path, numerics, name, img.stride, img.data.ctypes.data % 16, d)
         checked += 1
     assert checked > 40
 

@@ -508,3 +508,24 @@ def test_async_round_robin_over_devices_option():
     for i, im in enumerate(imgs):
         err, got = out[i]
         assert err is None and max_code_diff(got, oracle_resize(im, 48, 32)) == 0
+
+
+def test_row_chunks_with_non_monotonic_left_after_zero_trimming():
+    """Found by the long fuzz sweep (seed 5558): filters that are exactly 0 at integer offsets (catmulrom, mitchel,
+    cubic) get their zero end taps trimmed (src/resize.cc:31-34), which in an upscale can make left[y] > left[y+1].
+    A row chunk must start at the smallest left of ALL its rows, not at its first row's."""
+    rng = np.random.default_rng(5558)
+    for pixel in ("r16", "rgba", "rgb", "grey"):
+        for (sw, sh, dw, dh) in [(36, 38, 5, 133), (20, 31, 40, 124), (64, 17, 64, 200), (9, 40, 9, 161)]:
+            img = rand_image(rng, sw, sh, pixel)
+            for filt in ("catmulrom", "mitchel", "cubic", "triangle"):
+                exp = oracle_resize(img, dw, dh, filt, 1.0)
+                for chunks in (0, 2, 5, 8):
+                    set_path(3)
+                    set_opt("row_chunks", chunks)
+                    try:
+                        got = picha_amd.resizeSync(img, {"width": dw, "height": dh, "filter": filt})
+                    except picha_amd.PichaError as e:
+                        assert "unsupported" in str(e)
+                        continue
+                    assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, filt, chunks, N.lib().picha_hip_last_kernel())
