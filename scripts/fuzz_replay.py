@@ -8,7 +8,7 @@ import test_gpu_fuzz as T
 from util import FILTERS, PIXELS, max_code_diff, oracle_resize, rand_image
 
 seed = int(sys.argv[1])
-rng = np.random.default_rng(1000 + seed)
+rng = np.random.default_rng(T.BASE + seed)
 for it in range(70):
     sw, sh, dw, dh = T._sizes(rng)
     pixel = PIXELS[int(rng.integers(0, 8))]
