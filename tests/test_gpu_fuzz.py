@@ -118,3 +118,87 @@ def test_random_color_converts_match_oracle():
         got = picha_amd.colorConvertSync(img, opts)
         exp = oracle_convert(img, dp, weights=wts)
         assert np.array_equal(payload(got), payload(exp)), (w, h, sp, dp, opts)
+
+
+N_DEV = int(os.environ.get("PICHA_FUZZ_DEVICE_SEEDS", "8"))
+
+
+@pytest.mark.parametrize("seed", range(N_DEV))
+def test_random_device_batches_match_oracle(seed):
+    """The device entry points with images placed at arbitrary byte offsets of one device buffer (base pointers that
+    are NOT 4-byte aligned, non-uniform spacing -> pointer tables, mixed geometries in one call -> grouping), including
+    the chained convert+resize call.  The host entry points always stage into 256-byte aligned arenas, so only this
+    test reaches the kernels' handling of unaligned image bases (re-based descriptors, alignment fall-backs)."""
+    import ctypes
+
+    import torch
+    rng = np.random.default_rng(BASE * 7 + seed)
+    L = N.lib()
+    pixel = PIXELS[int(rng.integers(0, 8))]
+    bpp = N.PIXEL_BYTES[pixel]
+    geoms = []
+    for _ in range(int(rng.integers(1, 3))):
+        f = int(rng.choice([2, 2, 3, 4, 0]))
+        if f:
+            dw, dh = int(rng.integers(4, 200)), int(rng.integers(4, 70))
+            geoms.append((dw * f, dh * f, dw, dh))
+        else:
+            geoms.append((int(rng.integers(8, 260)), int(rng.integers(8, 90)), int(rng.integers(4, 200)), int(rng.integers(4, 120))))
+    filt = [None, None, "cubic", "triangle", "lanczos", "mitchel"][int(rng.integers(0, 6))]
+    opts = {} if filt is None else {"filter": filt}
+    chain_to = PIXELS[int(rng.integers(0, 8))] if rng.integers(0, 3) == 0 else None
+    order = int(rng.integers(0, 2))
+    n = int(rng.integers(2, 7))
+    which = [int(rng.integers(0, len(geoms))) for _ in range(n)]
+    if rng.integers(0, 2):
+        which.sort()          # equal geometries adjacent: grouped launches
+    align = int(rng.choice([1, 1, 2, 4, 16]))      # byte alignment of every image base
+    if pixel.startswith("r16") or (chain_to or "").startswith("r16"):
+        align = max(align, 1)
+    srcs, items, off = [], [], int(rng.integers(0, 64))
+    for k in which:
+        sw, sh, dw, dh = geoms[k]
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 0, 4, 1, 2])))
+        off = (off + align - 1) // align * align
+        s_off = off
+        off += img.data.size + int(rng.integers(0, 9))
+        out_pixel = chain_to or pixel
+        d_stride = ((N.PIXEL_BYTES[out_pixel] * dw + 3) & ~3) + int(rng.choice([0, 0, 4, 1]))
+        off = (off + align - 1) // align * align
+        d_off = off
+        off += d_stride * dh + int(rng.integers(0, 9))
+        items.append((img, s_off, d_off, d_stride, dw, dh, out_pixel))
+    buf = torch.zeros(off + 64, dtype=torch.uint8, device="cuda")
+    base = buf.data_ptr()
+    for img, s_off, *_ in items:
+        buf[s_off:s_off + img.data.size].copy_(torch.from_numpy(img.data))
+    S = (N.CImage * n)()
+    D = (N.CImage * n)()
+    for i, (img, s_off, d_off, d_stride, dw, dh, out_pixel) in enumerate(items):
+        S[i] = N.CImage(base + s_off, img.stride, img.width, img.height, N.pixel_index(pixel))
+        D[i] = N.CImage(base + d_off, d_stride, dw, dh, N.pixel_index(out_pixel))
+    from picha_amd.api import _resize_options, color_settings
+    ftag, fscale = _resize_options(opts)
+    r, g, b = color_settings()
+    stream = torch.cuda.current_stream().cuda_stream
+    if chain_to:
+        N.check(L.picha_hip_convert_resize_device(n, S, D, order, r, g, b, ftag, fscale, stream))
+    else:
+        N.check(L.picha_hip_resize_device(n, S, D, ftag, fscale, stream))
+    torch.cuda.synchronize()
+    host = buf.cpu().numpy()
+    for i, (img, s_off, d_off, d_stride, dw, dh, out_pixel) in enumerate(items):
+        got = picha_amd.Image(width=dw, height=dh, pixel=out_pixel, stride=d_stride, data=host[d_off:d_off + d_stride * (dh - 1) + dw * N.PIXEL_BYTES[out_pixel]])
+        f, fs = opts.get("filter", "cubic"), (1.0 if opts else 0.70)
+        try:
+            if chain_to and order == 0:
+                exp = oracle_resize(oracle_convert(img, chain_to), dw, dh, f, fs)
+            elif chain_to:
+                exp = oracle_convert(oracle_resize(img, dw, dh, f, fs), chain_to)
+            else:
+                exp = oracle_resize(img, dw, dh, f, fs)
+        except RuntimeError:
+            continue
+        assert np.array_equal(payload(got), payload(exp)), "seed %d image %d: %s -> %s %dx%d -> %dx%d opts %r chain %r order %d align %d src+%d dst+%d stride %d/%d kernel %s: diff %d" % (
+            seed, i, pixel, out_pixel, img.width, img.height, dw, dh, opts, chain_to, order, align, s_off % 16, d_off % 16, img.stride, d_stride,
+            L.picha_hip_last_kernel().decode(), max_code_diff(got, exp))
