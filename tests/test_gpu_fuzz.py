@@ -202,3 +202,54 @@ def test_random_device_batches_match_oracle(seed):
         assert np.array_equal(payload(got), payload(exp)), "seed %d image %d: %s -> %s %dx%d -> %dx%d opts %r chain %r order %d align %d src+%d dst+%d stride %d/%d kernel %s: diff %d" % (
             seed, i, pixel, out_pixel, img.width, img.height, dw, dh, opts, chain_to, order, align, s_off % 16, d_off % 16, img.stride, d_stride,
             L.picha_hip_last_kernel().decode(), max_code_diff(got, exp))
+
+
+def test_random_async_requests_from_several_threads_match_oracle():
+    """The batching dispatcher under a random mixed load: resize / colorConvert / chained requests of random geometry
+    and format submitted concurrently from 4 threads; every callback must deliver the oracle's pixels."""
+    import threading
+    rng = np.random.default_rng(BASE + 424242)
+    reqs = []
+    for k in range(240 * max(1, N_SEEDS // 6)):
+        pixel = PIXELS[int(rng.integers(0, 8))]
+        sw, sh = int(rng.integers(4, 160)), int(rng.integers(4, 100))
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 0, 4, 1])))
+        kind = int(rng.integers(0, 3))
+        if kind == 0:
+            dw, dh = (max(1, sw // 2), max(1, sh // 2)) if rng.integers(0, 2) else (int(rng.integers(1, 120)), int(rng.integers(1, 80)))
+            o = {"width": dw, "height": dh}
+            if rng.integers(0, 2):
+                o["filter"] = FILTERS[int(rng.integers(0, 6))]
+            try:
+                want = oracle_resize(img, dw, dh, o.get("filter", "cubic"), 1.0 if "filter" in o else 0.70)
+            except RuntimeError:
+                continue
+            reqs.append((picha_amd.resize, img, o, want))
+        elif kind == 1:
+            to = PIXELS[int(rng.integers(0, 8))]
+            reqs.append((picha_amd.colorConvert, img, {"pixel": to}, oracle_convert(img, to)))
+        else:
+            to = PIXELS[int(rng.integers(0, 8))]
+            dw, dh = int(rng.integers(1, 90)), int(rng.integers(1, 60))
+            try:
+                want = oracle_resize(oracle_convert(img, to), dw, dh, "cubic", 0.70)
+            except RuntimeError:
+                continue
+            reqs.append((picha_amd.convertResize, img, {"pixel": to, "width": dw, "height": dh}, want))
+    results, lock = {}, threading.Lock()
+
+    def submit(tid):
+        for i in range(tid, len(reqs), 4):
+            fn, img, o, _ = reqs[i]
+            fn(img, o, (lambda k: (lambda e, r: results.__setitem__(k, (e, r))))(i))
+    threads = [threading.Thread(target=submit, args=(t,)) for t in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    picha_amd.drain()
+    assert len(results) == len(reqs)
+    for i, (fn, img, o, want) in enumerate(reqs):
+        err, got = results[i]
+        assert err is None, (i, err)
+        assert np.array_equal(payload(got), payload(want)), (i, fn.__name__, img.pixel, img.width, img.height, o)
