@@ -8,9 +8,10 @@ src = DeviceBatch(256, 3840, 2160, 'rgba').fill_random(1)
 dst = DeviceBatch(256, 1920, 1080, 'rgba')
 plan = ResizePlan(src, dst)
 torch.cuda.synchronize()
-evs = [torch.cuda.Event(enable_timing=True) for _ in range(61)]
+NL = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+evs = [torch.cuda.Event(enable_timing=True) for _ in range(NL + 1)]
 evs[0].record()
-for i in range(60):
+for i in range(NL):
     plan.run(); evs[i + 1].record()
 torch.cuda.synchronize()
-print(' '.join('%.3f' % evs[i].elapsed_time(evs[i + 1]) for i in range(60)))
+print(' '.join('%.3f' % evs[i].elapsed_time(evs[i + 1]) for i in range(NL)))
