@@ -121,7 +121,10 @@ int picha_hip_device_arch(char *buf, size_t len);
  *                flavour of the resize kernels, at most one code value from the reference
  *                (environment: PICHA_HIP_NUMERICS=fma sets the initial value)
  *   "path"       0 = auto, 1 = force the two-pass scratch kernels, 2 = force a fused kernel (error if
- *                none applies), 3 = fused but never the streaming kernel (LDS-ring kernel)
+ *                none applies), 3 = the LDS-ring span kernel (never the streaming or accumulator kernels),
+ *                4 = the accumulator kernel (error if the tap table is not representable)
+ *   "acc"        accumulator kernel: 0 = auto (when the span kernel's ring would be large), 1 = whenever
+ *                representable, 2 = never
  *   "per_lane"   0 = auto, else output columns per lane for the fused kernels (1, 2, 4)
  *   "row_chunks" 0 = auto, else number of row chunks per image for the fused kernels
  *   "stream_rot" 0 = auto, 1 / 2 = force the rotating-accumulator / unrolled variant of the streaming kernel

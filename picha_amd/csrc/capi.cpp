@@ -74,6 +74,7 @@ long g_opt_async_devices = [] {
     const char *e = getenv("PICHA_HIP_ASYNC_DEVICES");
     return e ? std::max(0L, atol(e)) : 0L;
 }();
+long g_opt_acc = 0;         // accumulator kernel: 0 auto (when the span kernel's ring would be large), 1 whenever representable, 2 never
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 long g_opt_stream_rot = 0;  // 0 auto, 1 force the rotating-accumulator streaming variant, 2 force the unrolled one
 long g_opt_dpp = 0;         // 0 auto, 1 prefer / 2 forbid the cross-lane pixel-sharing streaming kernel
@@ -103,6 +104,14 @@ struct DeviceAxis {
         int base = 0;                  // output y reads source rows step*y + base + j
     };
     std::map<std::pair<int, int>, YStream> ystreams;
+    // accumulator kernel, y role: per-source-row records for `nacc` round-robin accumulators, built on demand
+    struct YRows {
+        bool ok = false;
+        void *blob = nullptr;
+        int32_t *rec = nullptr;    // [src + 8][2 * nacc]: weights (float bits), then completing output row or -1
+        int32_t *range = nullptr;  // [dst][2]: first source row needed by this or any later output, last row so far
+    };
+    std::map<int, YRows> yrows;
 
     DeviceAxis() = default;
     DeviceAxis(const DeviceAxis &) = delete;
@@ -111,6 +120,7 @@ struct DeviceAxis {
         if (blob) (void)hipFree(blob);
         for (auto &kv : xtables) if (kv.second.blob) (void)hipFree(kv.second.blob);
         for (auto &kv : ystreams) if (kv.second.blob) (void)hipFree(kv.second.blob);
+        for (auto &kv : yrows) if (kv.second.blob) (void)hipFree(kv.second.blob);
     }
     // fused, y role
     int4 *y_info = nullptr;
@@ -396,6 +406,52 @@ int get_ystream(DeviceCtx *ctx, DeviceAxis *ay, int step, int taps, const Device
     return PICHA_OK;
 }
 
+// Per-source-row view of the vertical table for the accumulator kernel: output y accumulates in register set
+// y % nacc while source rows left[y] .. left[y] + count[y] - 1 go by.  Representable when the vertical windows are
+// plain consecutive rows (no ring aliasing, src/resize.cc:52-64 quirk) and outputs y and y + nacc are never pending
+// at the same time.
+int get_yrows(DeviceCtx *ctx, DeviceAxis *ay, int nacc, const DeviceAxis::YRows **out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto it = ay->yrows.find(nacc);
+    if (it != ay->yrows.end()) { *out = &it->second; return PICHA_OK; }
+    DeviceAxis::YRows yr;
+    const AxisTaps &t = ay->host;
+    const int dst = t.dst_size, src = t.src_size, T = t.taps;
+    bool ok = true;
+    for (int y = 0; y < dst && ok; ++y) {
+        for (int j = 0; j < t.count[y] && ok; ++j)
+            if (t.eff[(size_t)y * T + j] != t.left[y] + j) ok = false;  // ring aliasing: not representable
+        if (y >= nacc && t.left[y - nacc] + t.count[y - nacc] - 1 >= t.left[y]) ok = false;  // accumulator still busy
+    }
+    yr.ok = ok;
+    if (ok) {
+        const int rows = src + 8;  // ghost rows past the image: empty records
+        const size_t rec_words = (size_t)rows * 2 * nacc;
+        std::vector<int32_t> tab(rec_words + (size_t)dst * 2, 0);
+        for (int r = 0; r < rows; ++r)
+            for (int a = 0; a < nacc; ++a) tab[(size_t)r * 2 * nacc + nacc + a] = -1;
+        for (int y = 0; y < dst; ++y) {
+            const int a = y % nacc;
+            for (int j = 0; j < t.count[y]; ++j) {
+                const float w = t.weight[(size_t)y * T + j];
+                memcpy(&tab[(size_t)(t.left[y] + j) * 2 * nacc + a], &w, 4);
+            }
+            tab[(size_t)(t.left[y] + t.count[y] - 1) * 2 * nacc + nacc + a] = y;
+        }
+        int32_t *range = tab.data() + rec_words;
+        for (int y = 0; y < dst; ++y) { range[2 * y] = t.left[y]; range[2 * y + 1] = t.left[y] + t.count[y] - 1; }
+        for (int y = dst - 2; y >= 0; --y) range[2 * y] = std::min(range[2 * y], range[2 * (y + 1)]);   // see y_info.x
+        for (int y = 1; y < dst; ++y) range[2 * y + 1] = std::max(range[2 * y + 1], range[2 * (y - 1) + 1]);
+        HIP_TRY(hipMalloc(&yr.blob, tab.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(yr.blob, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        yr.rec = static_cast<int32_t *>(yr.blob);
+        yr.range = yr.rec + rec_words;
+    }
+    auto ins = ay->yrows.emplace(nacc, yr);
+    *out = &ins.first->second;
+    return PICHA_OK;
+}
+
 // ---- validation ----------------------------------------------------------------------------------
 int check_src(const picha_image *im) {
     // jsImageToNativeImage (src/picha.cc:61-85): valid pixel, data present, height != 0
@@ -470,13 +526,14 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (rc) return rc;
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
-    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd;
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
         opt_rot = g_opt_stream_rot;
         opt_dpp = g_opt_dpp;
         opt_xcd = g_opt_xcd_remap;
+        opt_acc = g_opt_acc;
     }
     const int fma = opt_numerics == 1 ? 1 : 0;
     const int is16 = pixel >= PICHA_R16;
@@ -494,7 +551,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     }
     int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps, pixel);  // includes alignment room where needed
     const DeviceAxis::XTable *xt = nullptr;
-    if (fused_ok && opt_per_lane != 1) {
+    if (fused_ok && opt_per_lane != 1 && opt_path != 4) {
         // integer decimation / interpolation step of the tap windows
         const int st = std::max(1, (int)std::lround((double)s0.width / d0.width));
         static const int cand[] = {2, 4};
@@ -510,7 +567,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         }
     }
     // ---- streaming kernel (uniform tables in x and y, no LDS): preferred when available
-    if (fused_ok && opt_path != 1 && opt_path != 3) {
+    if (fused_ok && opt_path != 1 && opt_path != 3 && opt_path != 4) {
         const int sx = std::max(1, (int)std::lround((double)s0.width / d0.width));
         const int sy = std::max(1, (int)std::lround((double)s0.height / d0.height));
         // lane layouts, measured on cfg2 with the XCD-contiguous workgroup order (profiles/r01_ab_xcd_remap.txt): two
@@ -611,7 +668,31 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             return PICHA_OK;
         }
     }
-    if (fused_ok && !xt) {
+    // ---- accumulator kernel (no ring): any downscale whose span-kernel ring would be large.  The ring costs
+    // (window rows) x 64 lanes x 4..16 B of LDS per wave and caps the occupancy (a 7.5x thumbnail: 22 KB per wave,
+    // 7 waves per CU); the accumulator kernel keeps nacc x channels registers instead.
+    const DeviceAxis::YRows *yr = nullptr;
+    const DeviceAxis::XTable *xa = nullptr;
+    int nacc = 0;
+    constexpr int kAccMinRing = 1;  // measured faster than the span kernel for every ring size it was tried on (profiles/r01_survey_acc_vs_span.txt)
+    if (fused_ok && per_lane == 1 && opt_path != 1 && opt_path != 3 && opt_acc != 2 && ktaps > 0 &&
+        (opt_acc == 1 || opt_path == 4 || ring >= kAccMinRing)) {
+        for (int na : {4, 6}) {
+            if (!acc_supported(pixel, ktaps, na)) break;
+            const DeviceAxis::YRows *cand = nullptr;
+            rc = get_yrows(ctx, ay, na, &cand);
+            if (rc) return rc;
+            if (cand->ok) { yr = cand; nacc = na; break; }
+        }
+        if (yr) {
+            rc = get_xtable(ctx, ax, 1, 1, ktaps, xw_mode, is16, &xa, fused_x_bytespan(ktaps, pixel) ? kBytes[pixel] : 0);
+            if (rc) return rc;
+            if (!xa->ok) yr = nullptr;
+        }
+    }
+    if (opt_path == 4 && !yr) return fail(PICHA_ERR_ARGUMENT, "accumulator kernel forced but unsupported for this geometry");
+    const bool use_acc = yr != nullptr;
+    if (fused_ok && !xt && !use_acc) {
         fused_ok = ktaps > 0 && fused_supported(pixel, ktaps, ay->host.taps, ring, 1);
         if (fused_ok) {
             rc = get_xtable(ctx, ax, 1, 1, ktaps, xw_mode, is16, &xt, fused_x_bytespan(ktaps, pixel) ? kBytes[pixel] : 0);
@@ -620,7 +701,8 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         }
     }
     if ((opt_path == 2 || opt_path == 3) && !fused_ok) return fail(PICHA_ERR_ARGUMENT, "fused kernel forced but unsupported for this geometry");
-    const bool use_fused = fused_ok && opt_path != 1;
+    const bool use_fused = use_acc || (fused_ok && opt_path != 1);
+    if (use_acc) xt = xa;
 
     if (use_fused) {
         FusedParams p{};
@@ -650,6 +732,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         p.y_taps = ay->host.taps; p.y_pad = ay->y_pad;
         p.ring_slots = ring;
         p.xcd_remap = opt_xcd == 1 ? 1 : 0;
+        if (use_acc) { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; p.x_per_lane = 1; p.x_step = 1; }
         // row chunks: enough waves to fill 256 CUs several times over, chunks not too short
         const long long col_waves = (xt->groups + 63) / 64;
         long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
@@ -664,7 +747,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             q.n_images = m;
             if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
             else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
-            HIP_TRY(launch_resize_fused(pixel, q, s, &g_last_kernel));
+            HIP_TRY(use_acc ? launch_resize_acc(pixel, q, s, &g_last_kernel) : launch_resize_fused(pixel, q, s, &g_last_kernel));
             done += m;
         }
         if (tab.used) return temp_release(ctx->tables, s);
@@ -976,6 +1059,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "stream_rot") == 0) { g_opt_stream_rot = value; return PICHA_OK; }
     if (strcmp(key, "dpp") == 0) { g_opt_dpp = value; return PICHA_OK; }
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
+    if (strcmp(key, "acc") == 0) { g_opt_acc = value; return PICHA_OK; }
     if (strcmp(key, "async_devices") == 0) { g_opt_async_devices = value; return PICHA_OK; }
     if (strcmp(key, "chain_window_mb") == 0) { g_opt_chain_window_mb = value; return PICHA_OK; }
     return fail(PICHA_ERR_ARGUMENT, "unknown option %s", key);
@@ -990,6 +1074,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "stream_rot") == 0) return g_opt_stream_rot;
     if (strcmp(key, "dpp") == 0) return g_opt_dpp;
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
+    if (strcmp(key, "acc") == 0) return g_opt_acc;
     if (strcmp(key, "async_devices") == 0) return g_opt_async_devices;
     if (strcmp(key, "chain_window_mb") == 0) return g_opt_chain_window_mb;
     return -1;

@@ -70,7 +70,16 @@ struct FusedParams {
     int ring_slots;
     int rows_per_chunk, n_chunks;
     int xcd_remap;  // 1: XCD-contiguous workgroup order (see kernels_impl.inc, xcd_contiguous_block)
+    // accumulator kernel (resize_acc_kernel): per SOURCE row a record of 2*nacc dwords — the weight this row has in each
+    // of the nacc pending outputs (output y lives in accumulator y % nacc) and, per accumulator, the output row that
+    // COMPLETES with this source row (or -1); per output row {first source row needed by it or any later row, last}
+    const int32_t *yrow_rec;    // [src_h + 8][2 * nacc]
+    const int32_t *yrow_range;  // [dst_h][2]
+    int nacc;
 };
+// Accumulator kernel: instantiations exist for x tap buckets >= 4 and nacc in {4, 6}.
+bool acc_supported(int pixel, int x_taps_bucket, int nacc);
+hipError_t launch_resize_acc(int pixel, const FusedParams &p, hipStream_t s, const char **kernel_name);
 // True if a fused instantiation exists for this format / tap counts and its LDS ring fits.
 bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots, int per_lane);
 bool fused_multi_supported(int pixel, int per_lane, int step, int x_taps);

@@ -6,7 +6,9 @@
 namespace picha_hip {
 
 // defined in kernels_span.hip, one translation unit per pixel format
-#define PICHA_DECL_SPAN(N) hipError_t launch_span_p1_pixel##N(const FusedParams &p, hipStream_t s, const char **name);
+#define PICHA_DECL_SPAN(N)                                                                           \
+    hipError_t launch_span_p1_pixel##N(const FusedParams &p, hipStream_t s, const char **name);      \
+    hipError_t launch_acc_p1_pixel##N(const FusedParams &p, hipStream_t s, const char **name);
 PICHA_DECL_SPAN(0) PICHA_DECL_SPAN(1) PICHA_DECL_SPAN(2) PICHA_DECL_SPAN(3)
 PICHA_DECL_SPAN(4) PICHA_DECL_SPAN(5) PICHA_DECL_SPAN(6) PICHA_DECL_SPAN(7)
 #undef PICHA_DECL_SPAN
@@ -91,6 +93,20 @@ int fused_x_bucket(int x_taps, int pixel) {
 bool fused_x_bytespan(int x_taps_bucket, int pixel) {  // aligned fetch: the host must align the windows
     const int bpp = pixel_channels(pixel) * (pixel_is16(pixel) ? 2 : 1);
     return bpp % 4 != 0 && !span_rotate(bpp, x_taps_bucket);
+}
+
+bool acc_supported(int pixel, int x_taps_bucket, int nacc) {
+    if (pixel < 0 || pixel > 7 || (nacc != 4 && nacc != 6)) return false;
+    switch (x_taps_bucket) { case 4: case 5: case 6: case 7: case 8: case 10: case 12: case 16: case 20: case 24: case 32: case 36: return true; }
+    return false;
+}
+hipError_t launch_resize_acc(int pixel, const FusedParams &p, hipStream_t s, const char **name) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return launch_acc_p1_pixel##N(p, s, name);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return hipErrorInvalidValue;
 }
 
 bool fused_multi_supported(int pixel, int per_lane, int step, int x_taps) {

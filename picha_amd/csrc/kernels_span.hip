@@ -13,4 +13,7 @@ namespace picha_hip {
 hipError_t PICHA_CAT(launch_span_p1_pixel, PICHA_SPAN_PIXEL)(const FusedParams &p, hipStream_t s, const char **name) {
     return launch_span_p1<pixel_channels(PICHA_SPAN_PIXEL), pixel_is16(PICHA_SPAN_PIXEL)>(p, s, name);
 }
+hipError_t PICHA_CAT(launch_acc_p1_pixel, PICHA_SPAN_PIXEL)(const FusedParams &p, hipStream_t s, const char **name) {
+    return launch_acc_p1<pixel_channels(PICHA_SPAN_PIXEL), pixel_is16(PICHA_SPAN_PIXEL)>(p, s, name);
+}
 }  // namespace picha_hip

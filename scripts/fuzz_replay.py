@@ -26,9 +26,9 @@ for it in range(70):
         exp = oracle_resize(img, dw, dh, filt, fscale)
     except RuntimeError:
         continue
-    path = int(rng.choice([0, 0, 1, 3])); numerics = int(rng.integers(0, 4) == 0)
+    path = int(rng.choice([0, 0, 1, 3, 4])); numerics = int(rng.integers(0, 4) == 0)
     knobs = dict(path=path, numerics=numerics, per_lane=int(rng.choice([0, 0, 1, 2, 4])), row_chunks=int(rng.choice([0, 0, 1, 2, 7])),
-                 stream_rot=int(rng.choice([0, 1, 2])), xcd_remap=int(rng.choice([0, 1, 2])))
+                 stream_rot=int(rng.choice([0, 1, 2])), xcd_remap=int(rng.choice([0, 1, 2])), acc=int(rng.choice([0, 0, 1, 2])))
     for k, v in knobs.items(): T.set_opt(k, v)
     try:
         got = picha_amd.resizeSync(img, opts)

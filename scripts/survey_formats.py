@@ -26,7 +26,11 @@ for name, sw, sh, dw, dh, o in cases:
         for path, xcd in [(a, b) for a in paths for b in xcds]:
             N.check(N.lib().picha_hip_set_option(b'path', path))
             N.check(N.lib().picha_hip_set_option(b'xcd_remap', xcd))
-            for _ in range(3): plan.run()
+            try:
+                for _ in range(3): plan.run()
+            except N.PichaError as e:
+                print('%-16s %-14s path %d: %s' % (name, pixel, path, e), flush=True)
+                continue
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

@@ -17,7 +17,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc"):
         set_opt(k, 0)
 
 
@@ -77,7 +77,7 @@ def test_random_resizes_match_oracle(seed):
             with pytest.raises(picha_amd.PichaError):
                 picha_amd.resizeSync(img, opts)
             continue
-        path = int(rng.choice([0, 0, 1, 3]))
+        path = int(rng.choice([0, 0, 1, 3, 4]))
         numerics = int(rng.integers(0, 4) == 0)
         set_opt("path", path)
         set_opt("numerics", numerics)
@@ -85,10 +85,11 @@ def test_random_resizes_match_oracle(seed):
         set_opt("row_chunks", int(rng.choice([0, 0, 1, 2, 7])))
         set_opt("stream_rot", int(rng.choice([0, 1, 2])))
         set_opt("xcd_remap", int(rng.choice([0, 1, 2])))
+        set_opt("acc", int(rng.choice([0, 0, 1, 2])))
         try:
             got = picha_amd.resizeSync(img, opts)
         except picha_amd.PichaError as e:
-            if path != 3 or "unsupported" not in str(e):
+            if path not in (3, 4) or "unsupported" not in str(e):
                 raise
             set_opt("path", 0)  # forcing a fused kernel is legitimately refused (tap count, alignment): use auto
             path = 0

@@ -422,7 +422,7 @@ def test_resize_subdword_multi_output_streaming_kernel(pixel):
     resize_batch(src, out=odd)
     torch.cuda.synchronize()
     name = N.lib().picha_hip_last_kernel().decode()
-    assert name.startswith("resize_span"), name
+    assert not name.startswith("resize_stream"), name
     for i in range(2):
         exp = oracle_resize(src.image_host(i), 128, 48)
         assert np.array_equal(payload(odd.image_host(i)), payload(exp)), (pixel, i, name)
@@ -435,11 +435,12 @@ def test_kernel_selection_for_the_baseline_workloads():
     cases = [
         ("rgba", 384, 216, 192, 108, {}, "resize_stream<ch4,u8,P2,SX2,TX5,SY2,TY5"),                     # cfg2
         ("rgba", 384, 216, 192, 108, {"filter": "cubic"}, "resize_stream<ch4,u8,P2,SX2,TX7,SY2,TY7"),     # cfg2, 7 taps
-        ("grey", 3840, 216, 512, 51, {"filter": "lanczos"}, "resize_span<ch1,u8,P1,S1,TX36,TY32"),        # cfg3b (x: 7.5x)
+        ("grey", 3840, 216, 512, 51, {"filter": "lanczos"}, "resize_acc<ch1,u8,TX36,NACC6"),              # cfg3b (x: 7.5x, y: 4.2x)
         ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_stream<ch4,u16,P1,SX4,TX15,SY4,TY15"),  # cfg5
         ("rgb", 384, 216, 192, 108, {}, "resize_stream<ch3,u8,P4,SX2,TX5,SY2,TY5"),
         ("grey", 384, 216, 192, 108, {}, "resize_stream<ch1,u8,P4,SX2,TX5,SY2,TY5"),
-        ("rgb", 300, 200, 130, 90, {}, "resize_span<ch3,u8,P1"),                                         # non-integer scale
+        ("rgb", 300, 200, 130, 90, {}, "resize_acc<ch3,u8,TX"),                                          # non-integer scale
+        ("rgba", 200, 100, 500, 250, {}, "resize_span<ch4,u8,P"),                                        # upscale: ring kernel
     ]
     for pixel, sw, sh, dw, dh, opts, want in cases:
         img = rand_image(rng, sw, sh, pixel)
@@ -529,3 +530,47 @@ def test_row_chunks_with_non_monotonic_left_after_zero_trimming():
                         assert "unsupported" in str(e)
                         continue
                     assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, filt, chunks, N.lib().picha_hip_last_kernel())
+
+
+@pytest.mark.parametrize("pixel", PIXELS)
+def test_accumulator_kernel_matches_oracle(pixel):
+    """resize_acc_kernel (no ring: nacc register accumulators per lane, per-source-row weight records): forced with
+    path = 4 over downscales of several strengths and filters, row chunking, both numerics; where the vertical table is
+    not representable (ring aliasing, too many pending rows) the library must refuse, and auto mode must still be right."""
+    rng = np.random.default_rng(600 + PIXELS.index(pixel))
+    ran = 0
+    for (sw, sh, dw, dh) in [(300, 200, 40, 27), (640, 480, 96, 64), (150, 120, 20, 16), (257, 131, 64, 50), (97, 300, 31, 23),
+                             (512, 64, 128, 32)]:
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 4, 1 if not pixel.startswith("r16") else 2])))
+        for filt, fscale in (("cubic", 0.70), ("lanczos", 1.0), ("mitchel", 1.0), ("box", 1.0), ("triangle", 1.0)):
+            opts = {"width": dw, "height": dh}
+            if filt != "cubic":
+                opts["filter"] = filt
+            try:
+                exp = oracle_resize(img, dw, dh, filt, fscale)
+            except RuntimeError:
+                continue
+            for chunks in (0, 1, 3):
+                set_opt("row_chunks", chunks)
+                set_path(4)
+                try:
+                    got = picha_amd.resizeSync(img, opts)
+                except picha_amd.PichaError as e:
+                    assert "unsupported" in str(e), str(e)
+                    set_path(0)
+                    got = picha_amd.resizeSync(img, opts)
+                else:
+                    name = N.lib().picha_hip_last_kernel().decode()
+                    assert name.startswith("resize_acc<ch%d" % N.PIXEL_CHANNELS[pixel]), name
+                    ran += 1
+                assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, filt, chunks, N.lib().picha_hip_last_kernel())
+            set_opt("row_chunks", 0)
+            set_path(4)
+            set_opt("numerics", 1)
+            try:
+                got = picha_amd.resizeSync(img, opts)
+                assert max_code_diff(got, exp) <= 1, (pixel, sw, sh, dw, dh, filt, "fma")
+            except picha_amd.PichaError as e:
+                assert "unsupported" in str(e)
+            set_opt("numerics", 0)
+    assert ran >= 10, ran
