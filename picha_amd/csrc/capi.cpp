@@ -733,9 +733,18 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         p.ring_slots = ring;
         p.xcd_remap = opt_xcd == 1 ? 1 : 0;
         if (use_acc) { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; p.x_per_lane = 1; p.x_step = 1; }
-        // row chunks: enough waves to fill 256 CUs several times over, chunks not too short
+        // row chunks: enough waves to fill 256 CUs several times over (~32 K), but every chunk re-resamples the `ring`
+        // source rows above its first output: keep that halo under ~6 % of the chunk's own source rows unless the
+        // launch would then have fewer than ~8 K waves (4K -> 512x288 thumbnails: 18 -> 6 chunks, -5 %)
         const long long col_waves = (xt->groups + 63) / 64;
         long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
+        if (opt_chunks <= 0) {
+            const double src_rows_per_out = std::max(1.0, (double)s0.height / d0.height);
+            const long long min_rows = (long long)std::ceil(ring / (0.06 * src_rows_per_out));
+            const long long by_halo = std::max<long long>(1, d0.height / std::max<long long>(16, min_rows));
+            const long long by_fill = (8192 + n * col_waves - 1) / (n * col_waves);
+            chunks = std::min(chunks, std::max(by_halo, by_fill));
+        }
         chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
         p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
         p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
