@@ -675,17 +675,18 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     const DeviceAxis::XTable *xa = nullptr;
     int nacc = 0;
     constexpr int kAccMinRing = 1;  // measured faster than the span kernel for every ring size it was tried on (profiles/r01_survey_acc_vs_span.txt)
-    if (fused_ok && per_lane == 1 && opt_path != 1 && opt_path != 3 && opt_acc != 2 && ktaps > 0 &&
+    const int ataps = fused_x_bucket(ax->host.taps, pixel, true);  // the accumulator kernel's own (finer) x bucket
+    if (fused_ok && per_lane == 1 && opt_path != 1 && opt_path != 3 && opt_acc != 2 && ataps > 0 &&
         (opt_acc == 1 || opt_path == 4 || ring >= kAccMinRing)) {
         for (int na : {4, 6}) {
-            if (!acc_supported(pixel, ktaps, na)) break;
+            if (!acc_supported(pixel, ataps, na)) break;
             const DeviceAxis::YRows *cand = nullptr;
             rc = get_yrows(ctx, ay, na, &cand);
             if (rc) return rc;
             if (cand->ok) { yr = cand; nacc = na; break; }
         }
         if (yr) {
-            rc = get_xtable(ctx, ax, 1, 1, ktaps, xw_mode, is16, &xa, fused_x_bytespan(ktaps, pixel) ? kBytes[pixel] : 0);
+            rc = get_xtable(ctx, ax, 1, 1, ataps, xw_mode, is16, &xa, fused_x_bytespan(ataps, pixel) ? kBytes[pixel] : 0);
             if (rc) return rc;
             if (!xa->ok) yr = nullptr;
         }
@@ -702,7 +703,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     }
     if ((opt_path == 2 || opt_path == 3) && !fused_ok) return fail(PICHA_ERR_ARGUMENT, "fused kernel forced but unsupported for this geometry");
     const bool use_fused = use_acc || (fused_ok && opt_path != 1);
-    if (use_acc) xt = xa;
+    if (use_acc) { xt = xa; ktaps = ataps; }
 
     if (use_fused) {
         FusedParams p{};

@@ -84,7 +84,7 @@ hipError_t launch_resize_acc(int pixel, const FusedParams &p, hipStream_t s, con
 bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots, int per_lane);
 bool fused_multi_supported(int pixel, int per_lane, int step, int x_taps);
 // Kernel tap count for a table with x_taps taps (0: none).  Padded row length of the y tables.
-int fused_x_bucket(int x_taps, int pixel);
+int fused_x_bucket(int x_taps, int pixel, bool acc = false);
 // True if the kernel for that bucket fetches a sub-dword-pixel span as whole dwords: the host must then
 // keep every lane's window inside its row (shifted, zero-padded in front).
 bool fused_x_bytespan(int x_taps_bucket, int pixel);

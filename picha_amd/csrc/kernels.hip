@@ -77,17 +77,24 @@ hipError_t launch_resize_twopass(int pixel, const TwoPassParams &p, hipStream_t 
 
 int fused_y_pad(int y_taps) { return y_taps <= 8 ? 8 : (y_taps <= 16 ? 16 : 32); }
 
-int fused_x_bucket(int x_taps, int pixel) {
-    static const int buckets[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 36};
+// acc: the accumulator kernel has a finer bucket list above 12 taps (a long window's zero-padded slots are pure
+// VALU waste in a VALU-bound kernel; the span kernel keeps the coarse list, it has three y variants per bucket)
+int fused_x_bucket(int x_taps, int pixel, bool acc) {
+    static const int coarse[] = {1, 2, 3, 4, 5, 6, 7, 8, 10, 12, 16, 20, 24, 32, 36};
+    static const int fine[] = {4, 5, 6, 7, 8, 10, 12, 14, 16, 18, 20, 22, 24, 28, 32, 36};
+    const int *buckets = acc ? fine : coarse;
+    const int nb = acc ? int(sizeof fine / sizeof fine[0]) : int(sizeof coarse / sizeof coarse[0]);
     const int bpp = pixel_channels(pixel) * (pixel_is16(pixel) ? 2 : 1);
     if (bpp % 4 != 0) {  // sub-dword pixels: the rotated fetch takes the window as it is (see span_rotate)
-        for (int b : buckets)
-            if (x_taps <= b) { if (span_rotate(bpp, b)) return b; break; }
+        for (int i = 0; i < nb; ++i)
+            if (x_taps <= buckets[i]) { if (span_rotate(bpp, buckets[i])) return buckets[i]; break; }
     }
     // aligned fetch: room for moving the window start down to a 4-byte boundary, and a whole-dword window
     const int room = bpp % 4 == 0 ? 0 : (bpp % 2 ? 3 : 1);
-    for (int b : buckets)
+    for (int i = 0; i < nb; ++i) {
+        const int b = buckets[i];
         if (x_taps + room <= b && (b * bpp) % 4 == 0 && !span_rotate(bpp, b)) return b;
+    }
     return 0;
 }
 bool fused_x_bytespan(int x_taps_bucket, int pixel) {  // aligned fetch: the host must align the windows
@@ -97,7 +104,10 @@ bool fused_x_bytespan(int x_taps_bucket, int pixel) {  // aligned fetch: the hos
 
 bool acc_supported(int pixel, int x_taps_bucket, int nacc) {
     if (pixel < 0 || pixel > 7 || (nacc != 4 && nacc != 6)) return false;
-    switch (x_taps_bucket) { case 4: case 5: case 6: case 7: case 8: case 10: case 12: case 16: case 20: case 24: case 32: case 36: return true; }
+    switch (x_taps_bucket) {
+    case 4: case 5: case 6: case 7: case 8: case 10: case 12: case 14: case 16: case 18: case 20: case 22: case 24: case 28: case 32: case 36:
+        return true;
+    }
     return false;
 }
 hipError_t launch_resize_acc(int pixel, const FusedParams &p, hipStream_t s, const char **name) {
