@@ -15,6 +15,8 @@ cases = [('2x down', 3840, 2160, 1920, 1080, {}), ('3x down', 3840, 2160, 1280, 
          ('1.5x down', 1920, 1080, 1280, 720, {}), ('7.5x thumb', 3840, 2160, 512, 288, {}), ('2x up', 960, 540, 1920, 1080, {}),
          ('2x down lanczos', 3840, 2160, 1920, 1080, {'filter': 'lanczos'}), ('2x down triangle', 3840, 2160, 1920, 1080, {'filter': 'triangle'}),
          ('4x down mitchel', 3840, 2160, 960, 540, {'filter': 'mitchel'})]
+numerics = int(sys.argv[6]) if len(sys.argv) > 6 else 0
+N.check(N.lib().picha_hip_set_option(b'numerics', numerics))
 print('%-16s %-14s %-58s %8s %8s %6s' % ('case', 'pixel', 'kernel', 'ms', 'GB/s', 'frac'))
 for name, sw, sh, dw, dh, o in cases:
     if only and name not in only:
