@@ -675,7 +675,9 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     const DeviceAxis::XTable *xa = nullptr;
     int nacc = 0;
     constexpr int kAccMinRing = 1;  // measured faster than the span kernel for every ring size it was tried on (profiles/r01_survey_acc_vs_span.txt)
-    const int ataps = fused_x_bucket(ax->host.taps, pixel, true);  // the accumulator kernel's own (finer) x bucket
+    int ataps = fused_x_bucket(ax->host.taps, pixel, true);  // the accumulator kernel's own (finer) x bucket
+    const bool acc_long = ataps == 0 && ax->host.taps > 36 && ax->host.taps <= 128;
+    if (acc_long) ataps = (ax->host.taps + 15) / 16 * 16;  // long windows: LDS-resident weights, multiples of 16 taps
     if (fused_ok && per_lane == 1 && opt_path != 1 && opt_path != 3 && opt_acc != 2 && ataps > 0 &&
         (opt_acc == 1 || opt_path == 4 || ring >= kAccMinRing)) {
         for (int na : {4, 6}) {
@@ -686,7 +688,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             if (cand->ok) { yr = cand; nacc = na; break; }
         }
         if (yr) {
-            rc = get_xtable(ctx, ax, 1, 1, ataps, xw_mode, is16, &xa, fused_x_bytespan(ataps, pixel) ? kBytes[pixel] : 0);
+            rc = get_xtable(ctx, ax, 1, 1, ataps, xw_mode, is16, &xa, (!acc_long && fused_x_bytespan(ataps, pixel)) ? kBytes[pixel] : 0);
             if (rc) return rc;
             if (!xa->ok) yr = nullptr;
         }

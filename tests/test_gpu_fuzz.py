@@ -22,7 +22,10 @@ def _reset():
 
 
 def _sizes(rng):
-    kind = rng.integers(0, 8)
+    kind = rng.integers(0, 9)
+    if kind == 8:    # very strong horizontal downscale: windows of 37 .. 128+ taps (long-window accumulator kernel, two-pass)
+        dw, dh = int(rng.integers(1, 40)), int(rng.integers(1, 30))
+        return dw * int(rng.integers(13, 44)) + int(rng.integers(0, 9)), dh * int(rng.integers(1, 9)) + int(rng.integers(0, 4)), dw, dh
     if kind == 6:    # tall upscales: several row chunks, many outputs per source row
         sw, sh = int(rng.integers(1, 50)), int(rng.integers(8, 60))
         return sw, sh, int(rng.integers(1, 120)), sh * int(rng.integers(2, 6)) + int(rng.integers(0, 9))

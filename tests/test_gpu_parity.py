@@ -573,3 +573,33 @@ def test_accumulator_kernel_matches_oracle(pixel):
                 assert "unsupported" in str(e)
             set_opt("numerics", 0)
     assert ran >= 10, ran
+
+
+@pytest.mark.parametrize("pixel", PIXELS)
+def test_long_window_accumulator_kernel(pixel):
+    """Horizontal windows of more than 36 taps (downscales beyond ~9-13x): resize_acc_long_kernel keeps the x weights
+    in LDS and walks the window in segments.  Before it these geometries fell to the two-pass kernels."""
+    rng = np.random.default_rng(900 + PIXELS.index(pixel))
+    for (sw, sh, dw, dh, filt, fscale) in [(2000, 90, 100, 30, "cubic", 0.70),      # 20x: 57 taps -> 64
+                                             (1203, 77, 97, 11, "lanczos", 1.0),      # 12.4x, 2-lobe: 51 taps; y 7x
+                                             (3001, 40, 64, 9, "mitchel", 1.0),       # 47x: > 128 taps -> two-pass
+                                             (640, 33, 40, 8, "triangle", 1.0)]:      # 16x triangle: 33 taps (short kernel)
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8])))   # multiples of 8: the widest format's alignment rule
+        opts = {"width": dw, "height": dh}
+        if filt != "cubic":
+            opts["filter"] = filt
+        exp = oracle_resize(img, dw, dh, filt, fscale)
+        for chunks in (0, 2):
+            set_opt("row_chunks", chunks)
+            got = picha_amd.resizeSync(img, opts)
+            name = N.lib().picha_hip_last_kernel().decode()
+            assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, filt, chunks, name)
+            if sw in (2000, 1203):
+                assert name.startswith("resize_acc_long<ch%d" % N.PIXEL_CHANNELS[pixel]), name
+            if sw == 3001:
+                assert name == "twopass", name
+        set_opt("row_chunks", 0)
+        set_opt("numerics", 1)
+        got = picha_amd.resizeSync(img, opts)
+        assert max_code_diff(got, exp) <= 1, (pixel, sw, "fma", N.lib().picha_hip_last_kernel())
+        set_opt("numerics", 0)
