@@ -677,7 +677,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     constexpr int kAccMinRing = 1;  // measured faster than the span kernel for every ring size it was tried on (profiles/r01_survey_acc_vs_span.txt)
     int ataps = fused_x_bucket(ax->host.taps, pixel, true);  // the accumulator kernel's own (finer) x bucket
     const bool acc_long = ataps == 0 && ax->host.taps > 36 && ax->host.taps <= 128;
-    if (acc_long) ataps = (ax->host.taps + 15) / 16 * 16;  // long windows: LDS-resident weights, multiples of 16 taps
+    if (acc_long) {  // long windows: LDS-resident weights, tap count padded to half a load segment
+        const int half = acc_long_segment(kBytes[pixel]) / 2;
+        ataps = (ax->host.taps + half - 1) / half * half;
+    }
     if (fused_ok && per_lane == 1 && opt_path != 1 && opt_path != 3 && opt_acc != 2 && ataps > 0 &&
         (opt_acc == 1 || opt_path == 4 || ring >= kAccMinRing)) {
         for (int na : {4, 6}) {
