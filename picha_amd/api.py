@@ -31,22 +31,30 @@ _pending_lock = threading.Lock()
 _tokens = itertools.count(1)
 
 
-def _submit_async(submit, src, dst, cb):
-    """submit(done_ptr) -> status.  Calls cb(None, dst) or cb(err, None) from a library thread."""
-    token = next(_tokens)
-
-    def _done(user, status, err):
-        with _pending_lock:
-            _pending.pop(token, None)
-        if status == 0:
-            cb(None, dst)
-        else:
-            cb(PichaError((err or b"").decode() or N.lib().picha_hip_strerror(status).decode(), status), None)
-
-    c_done = N.DONE_FN(_done)
+def _on_done(user, status, err):
+    """The ONE trampoline every async request completes through (`user` = the request's token).  A module-level
+    CFUNCTYPE object lives as long as the module, so native code never returns through a freed closure."""
     with _pending_lock:
-        _pending[token] = (c_done, src, dst)
-    rc = submit(ctypes.cast(c_done, ctypes.c_void_p))
+        entry = _pending.pop(int(user or 0), None)
+    if entry is None:
+        return
+    cb, _src, dst = entry
+    if status == 0:
+        cb(None, dst)
+    else:
+        cb(PichaError((err or b"").decode() or N.lib().picha_hip_strerror(status).decode(), status), None)
+
+
+_DONE = N.DONE_FN(_on_done)
+_DONE_PTR = ctypes.cast(_DONE, ctypes.c_void_p)
+
+
+def _submit_async(submit, src, dst, cb):
+    """submit(done_ptr, user_ptr) -> status.  Calls cb(None, dst) or cb(err, None) from a library thread."""
+    token = next(_tokens)
+    with _pending_lock:
+        _pending[token] = (cb, src, dst)
+    rc = submit(_DONE_PTR, ctypes.c_void_p(token))
     if rc != 0:
         with _pending_lock:
             _pending.pop(token, None)
@@ -107,6 +115,8 @@ def _native_image(img):
 def _new_image(width, height, pixel):
     """newJsImage (src/picha.cc:119-133): stride = row_stride, data uninitialised."""
     stride = (N.PIXEL_BYTES[pixel] * width + 3) & ~3
+    if stride > 0x7FFFFFFF:  # the reference's int row_stride wraps here (src/picha.h:214); refuse instead
+        raise PichaError("invalid dimensions", N.ERR_INVALID_DIMENSIONS if hasattr(N, "ERR_INVALID_DIMENSIONS") else -2)
     data = np.empty(height * stride, dtype=np.uint8)
     return Image(width=width, height=height, pixel=pixel, stride=stride, data=data)
 
@@ -168,7 +178,7 @@ def resize(image, opts, cb):
     src, dst, ftag, fscale = _prepare_resize(image, opts, "expected: resize(image, opts, cb)")
     cdst = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index(dst.pixel))
     L = N.lib()
-    _submit_async(lambda done: L.picha_hip_resize_async(ctypes.byref(src[0]), ctypes.byref(cdst), ftag, fscale, done, None),
+    _submit_async(lambda done, user: L.picha_hip_resize_async(ctypes.byref(src[0]), ctypes.byref(cdst), ftag, fscale, done, user),
                   src, dst, cb)
 
 
@@ -216,8 +226,8 @@ def colorConvert(image, opts, cb):
     src, dst, cs = _prepare_convert(image, opts, "expected: colorConvert(image, opts, cb)")
     cdst = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index(dst.pixel))
     L = N.lib()
-    _submit_async(lambda done: L.picha_hip_color_convert_async(ctypes.byref(src[0]), ctypes.byref(cdst), cs[0], cs[1], cs[2],
-                                                               done, None), src, dst, cb)
+    _submit_async(lambda done, user: L.picha_hip_color_convert_async(ctypes.byref(src[0]), ctypes.byref(cdst), cs[0], cs[1], cs[2],
+                                                                     done, user), src, dst, cb)
 
 
 # ---- next to the path: both operations in one device round trip ---------------
@@ -252,8 +262,8 @@ def convertResize(image, opts, cb):
         raise PichaError("expected: convertResize(image, opts, cb)")
     src, dst, cdst, order, cs, ftag, fscale = _prepare_chain(image, opts, "expected: convertResize(image, opts, cb)")
     L = N.lib()
-    _submit_async(lambda done: L.picha_hip_convert_resize_async(ctypes.byref(src[0]), ctypes.byref(cdst), order, cs[0], cs[1],
-                                                                cs[2], ftag, fscale, done, None), src, dst, cb)
+    _submit_async(lambda done, user: L.picha_hip_convert_resize_async(ctypes.byref(src[0]), ctypes.byref(cdst), order, cs[0], cs[1],
+                                                                      cs[2], ftag, fscale, done, user), src, dst, cb)
 
 
 # ---- helpers exposed for tests / tools ----------------------------------------------------------

@@ -78,6 +78,9 @@ long g_opt_acc = 0;         // accumulator kernel: 0 auto (when the span kernel'
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 long g_opt_stream_rot = 0;  // 0 auto, 1 force the rotating-accumulator streaming variant, 2 force the unrolled one
 long g_opt_dpp = 0;         // 0 auto, 1 prefer / 2 forbid the cross-lane pixel-sharing streaming kernel
+long g_opt_sym = 0;         // symmetric-table streaming kernel (kernels_sym.hip): 0 auto (when available), 2 never
+long g_opt_sym_nbuf = 0;    // its row buffers in registers (0 auto)
+long g_opt_block_waves = 0; // its waves per workgroup (0 auto)
 
 // ---- per-device state ---------------------------------------------------------------------------
 struct DeviceAxis {
@@ -94,6 +97,11 @@ struct DeviceAxis {
         float *weight = nullptr;  // [taps][stride]
         int groups = 0, stride = 0;
         int l0 = 0;  // uniform_base tables: the common window offset (window of output x starts at step*x + l0)
+        // canonical outputs (resize_sym_kernel): outputs [c0, c1) all carry the weights of the middle output, those weights
+        // are symmetric (w[j] == w[taps-1-j] bitwise) and their windows start at step*x + xbase
+        bool sym = false;
+        int c0 = 0, c1 = 0, xbase = 0;
+        int32_t canon[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // float bits of w[0 .. (taps+1)/2) in this table's weight flavour
     };
     std::map<std::tuple<int, int, int, int, int>, XTable> xtables;
     // streaming kernel, y role: uniform-stride view of the table, built on demand per (step, taps)
@@ -102,6 +110,8 @@ struct DeviceAxis {
         void *blob = nullptr;
         float *step_weight = nullptr;  // [dst + (taps-1)/step][yw]
         int base = 0;                  // output y reads source rows step*y + base + j
+        bool sym = false;              // the interior rows have symmetric canonical weights (flag bit 1 of their step records)
+        int32_t canon[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     };
     std::map<std::pair<int, int>, YStream> ystreams;
     // accumulator kernel, y role: per-source-row records for `nacc` round-robin accumulators, built on demand
@@ -340,6 +350,26 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
     }
     xt.ok = ok;
     xt.l0 = uniform_base ? l0 : 0;
+    if (ok && !bytespan_bpp && !uniform_base && taps <= 15 && dst >= 4) {
+        int xb = INT32_MAX;
+        for (int i = 0; i < dst; ++i) xb = std::min(xb, t.left[i] - step * i);
+        const int mid = dst / 2;
+        auto wbits = [&](int i, int j) { int32_t b; memcpy(&b, &weight[(size_t)j * stride + i], 4); return b; };
+        auto is_canon = [&](int i) {
+            if (left[i / per_lane] + step * (i % per_lane) != step * i + xb) return false;
+            for (int j = 0; j < taps; ++j) if (wbits(i, j) != wbits(mid, j)) return false;
+            return true;
+        };
+        bool symm = is_canon(mid);
+        for (int j = 0; j < taps && symm; ++j) if (wbits(mid, j) != wbits(mid, taps - 1 - j)) symm = false;
+        if (symm) {
+            int c0 = mid, c1 = mid + 1;
+            while (c0 > 0 && is_canon(c0 - 1)) --c0;
+            while (c1 < dst && is_canon(c1)) ++c1;
+            xt.sym = true; xt.c0 = c0; xt.c1 = c1; xt.xbase = xb;
+            for (int j = 0; j < (taps + 1) / 2; ++j) xt.canon[j] = wbits(mid, j);
+        }
+    }
     if (ok) {
         const size_t lb = align_up(sizeof(int32_t) * groups, 256), wb = sizeof(float) * weight.size();
         std::vector<uint8_t> image(lb + wb, 0);
@@ -393,9 +423,33 @@ int get_ystream(DeviceCtx *ctx, DeviceAxis *ay, int step, int taps, const Device
                 tab[(size_t)(y + i) * yw + i * step + ph] = t.weight[(size_t)y * T + j];
             }
         }
-        for (int m = 1; m < nsteps; ++m) {
-            const int32_t same = memcmp(&tab[(size_t)m * yw], &tab[(size_t)(m - 1) * yw], sizeof(float) * npend * step) == 0;
-            memcpy(&tab[(size_t)m * yw + yw - 1], &same, 4);
+        // canonical rows: the weights of the middle output row in the uniform window, if symmetric; rows [c0, c1) carry them
+        int c0 = 0, c1 = 0;
+        if (taps <= 15 && dst >= 4) {
+            auto wpad = [&](int y, float *w) {
+                for (int j = 0; j < taps; ++j) w[j] = 0.0f;
+                const int first = t.left[y] - (step * y + base);
+                for (int j = 0; j < t.count[y]; ++j) w[first + j] = t.weight[(size_t)y * T + j];
+            };
+            float wc[16], wt[16];
+            const int mid = dst / 2;
+            wpad(mid, wc);
+            bool symm = true;
+            for (int j = 0; j < taps; ++j) if (memcmp(&wc[j], &wc[taps - 1 - j], 4) != 0) symm = false;
+            if (symm) {
+                auto is_canon = [&](int y) { wpad(y, wt); return memcmp(wt, wc, sizeof(float) * taps) == 0; };
+                c0 = mid; c1 = mid + 1;
+                while (c0 > 0 && is_canon(c0 - 1)) --c0;
+                while (c1 < dst && is_canon(c1)) ++c1;
+                ys.sym = true;
+                for (int j = 0; j < (taps + 1) / 2; ++j) memcpy(&ys.canon[j], &wc[j], 4);
+            }
+        }
+        for (int m = 0; m < nsteps; ++m) {
+            int32_t flags = 0;
+            if (m > 0 && memcmp(&tab[(size_t)m * yw], &tab[(size_t)(m - 1) * yw], sizeof(float) * npend * step) == 0) flags |= 1;
+            if (ys.sym && m - (npend - 1) >= c0 && m < c1) flags |= 2;  // outputs m, m-1, .., m-npend+1 all canonical
+            memcpy(&tab[(size_t)m * yw + yw - 1], &flags, 4);
         }
         HIP_TRY(hipMalloc(&ys.blob, tab.size() * sizeof(float)));
         HIP_TRY(hipMemcpy(ys.blob, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
@@ -462,7 +516,11 @@ int check_src(const picha_image *im) {
 int check_dst(const picha_image *im) {
     if (!im || !im->data || !valid_pixel(im->pixel)) return fail(PICHA_ERR_INVALID_IMAGE, "invalid image");
     if (im->width <= 0 || im->height <= 0) return fail(PICHA_ERR_INVALID_DIMENSIONS, "invalid dimensions");
-    if (im->stride < im->width * kBytes[im->pixel]) return fail(PICHA_ERR_INVALID_IMAGE, "invalid image");
+    // 64-bit arithmetic: width * bytes-per-pixel must fit the int stride (the reference's int row_stride wraps instead,
+    // src/picha.h:214 — a front end must not turn caller-supplied dimensions into a heap overflow)
+    const long long rw = (long long)im->width * kBytes[im->pixel];
+    if (rw > INT32_MAX - 3) return fail(PICHA_ERR_INVALID_DIMENSIONS, "invalid dimensions");
+    if ((long long)im->stride < rw) return fail(PICHA_ERR_INVALID_IMAGE, "invalid image");
     return PICHA_OK;
 }
 size_t image_span(const picha_image &im) {  // bytes from data to the end of the last row's payload
@@ -526,9 +584,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (rc) return rc;
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
-    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc;
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_sym_nbuf, opt_bw;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
+        opt_sym = g_opt_sym; opt_sym_nbuf = g_opt_sym_nbuf; opt_bw = g_opt_block_waves;
         opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
         opt_rot = g_opt_stream_rot;
         opt_dpp = g_opt_dpp;
@@ -585,6 +644,83 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         // cross-lane sharing variant (rgba8, exact 2x, 5 taps): fewest conversions per output and fully
         // coalesced loads, but measured 2-4 % SLOWER than the plain variant on cfg2 (the kernel is bound by
         // mixed read/write HBM traffic, not by the conversions it saves): opt-in only ("dpp" = 1)
+        // fills the parameters, sizes the row chunks and launches (resize_stream_kernel family or resize_sym_kernel)
+        auto launch_stream = [&](int pl, const DeviceAxis::XTable *cx, const DeviceAxis::YStream *cy, int rot, bool dpp, bool sym, int nbuf,
+                                 int bw) -> int {
+            StreamParams p{};
+            long long sp = 0, dp = 0;
+            TablePair tab;
+            std::unique_lock<std::mutex> temp_lock(ctx->temp_mu, std::defer_lock);
+            if (uniform_pitch(src, n, &sp) && uniform_pitch(dst, n, &dp)) {
+                p.src = static_cast<const uint8_t *>(s0.data);
+                p.dst = static_cast<uint8_t *>(d0.data);
+                p.src_pitch = sp; p.dst_pitch = dp;
+            } else {
+                temp_lock.lock();
+                int rc2 = make_tables(ctx, src, dst, n, s, &tab);
+                if (rc2) return rc2;
+                p.src_tab = tab.src; p.dst_tab = tab.dst;
+            }
+            p.src_stride = s0.stride; p.dst_stride = d0.stride;
+            p.src_w = s0.width; p.src_h = s0.height; p.dst_w = d0.width; p.dst_h = d0.height;
+            p.src_bytes = (unsigned)src_span; p.dst_bytes = (unsigned)dst_span;
+            p.x_left = cx->left; p.x_weight = cx->weight; p.x_taps = ax->host.taps;
+            p.x_per_lane = pl; p.x_step = sx; p.x_groups = cx->groups; p.xw_stride = cx->stride;
+            p.fma = fma;
+            p.y_step_weight = cy->step_weight; p.y_step = sy; p.y_taps = ay->host.taps; p.y_base = cy->base;
+            p.rot = rot;
+            p.dpp = dpp ? 1 : 0;
+            p.xcd_remap = opt_xcd == 1 || (opt_xcd == 0 && (pl >= 2 || dpp)) ? 1 : 0;
+            if (sym) {
+                memcpy(p.x_canon, cx->canon, sizeof p.x_canon);
+                memcpy(p.y_canon, cy->canon, sizeof p.y_canon);
+                p.cx0 = cx->c0; p.cx1 = cx->c1; p.x_base = cx->xbase;
+                p.nbuf = nbuf; p.block_waves = bw;
+            }
+            const long long col_waves = (cx->groups + 63) / 64;
+            // row chunks: at least ~32 K waves per launch, chunks of >= 16 output rows.  Every chunk re-reads and
+            // re-filters TY - SY halo rows.  The reference arithmetic is VALU-bound and wants few, long chunks; the fma
+            // flavour is memory-bound and gains 3 % from ~40-row chunks when the halo is short (in XCD-contiguous order
+            // the chunks in flight on an XCD then cover a compact piece of the image): profiles/r01_ab_row_chunks.txt
+            long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
+            if (opt_chunks <= 0 && fma && ay->host.taps - sy <= 5) chunks = std::max<long long>(chunks, (d0.height + 39) / 40);
+            chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
+            p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
+            p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
+            int done = 0;
+            while (done < n) {
+                const int m = std::min(n - done, 65535);
+                StreamParams q = p;
+                q.n_images = m;
+                if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
+                else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
+                HIP_TRY(sym ? launch_resize_sym_kernel(pixel, q, s, &g_last_kernel) : launch_resize_stream_kernel(pixel, q, s, &g_last_kernel));
+                done += m;
+            }
+            if (tab.used) return temp_release(ctx->tables, s);
+            return PICHA_OK;
+        };
+        // symmetric uniform tables (every picha filter at an integer scale): wave-uniform weights, products shared between
+        // outputs (kernels_sym.hip).  Needs at least one interior wave to pay.
+        if (opt_sym != 2 && opt_dpp != 1 && opt_rot == 0) {
+            const int cand_sym[] = {3, 4, 2, 1};
+            for (int pl : cand_sym) {
+                if (opt_per_lane > 0 && pl != opt_per_lane) continue;
+                if (subdword && ((pl * kBytes[pixel]) % 4 != 0 || !dst_dword_rows)) continue;
+                const int nb = opt_sym_nbuf > 0 ? (int)opt_sym_nbuf : 3;
+                const int bw = opt_bw > 0 ? (int)opt_bw : 2;
+                if (!sym_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps, nb, bw)) continue;
+                const DeviceAxis::XTable *cx = nullptr;
+                const DeviceAxis::YStream *cy = nullptr;
+                rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, xw_mode, is16, &cx);
+                if (rc) return rc;
+                rc = get_ystream(ctx, ay, sy, ay->host.taps, &cy);
+                if (rc) return rc;
+                if (!cx->ok || !cy->ok || !cx->sym || !cy->sym) continue;
+                if (cx->c1 - cx->c0 < 2 * 64 * pl) continue;
+                return launch_stream(pl, cx, cy, 0, false, true, nb, bw);
+            }
+        }
         bool want_dpp = opt_dpp == 1 && stream_dpp_supported(pixel, sx, ax->host.taps, sy, ay->host.taps);
         for (int pl : cand_s) {
             if (want_dpp && pl != 1) continue;
@@ -620,52 +756,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 if (rot < 0) continue;
             }
             if (!cx->ok || !cy->ok) continue;
-            StreamParams p{};
-            long long sp = 0, dp = 0;
-            TablePair tab;
-            std::unique_lock<std::mutex> temp_lock(ctx->temp_mu, std::defer_lock);
-            if (uniform_pitch(src, n, &sp) && uniform_pitch(dst, n, &dp)) {
-                p.src = static_cast<const uint8_t *>(s0.data);
-                p.dst = static_cast<uint8_t *>(d0.data);
-                p.src_pitch = sp; p.dst_pitch = dp;
-            } else {
-                temp_lock.lock();
-                rc = make_tables(ctx, src, dst, n, s, &tab);
-                if (rc) return rc;
-                p.src_tab = tab.src; p.dst_tab = tab.dst;
-            }
-            p.src_stride = s0.stride; p.dst_stride = d0.stride;
-            p.src_w = s0.width; p.src_h = s0.height; p.dst_w = d0.width; p.dst_h = d0.height;
-            p.src_bytes = (unsigned)src_span; p.dst_bytes = (unsigned)dst_span;
-            p.x_left = cx->left; p.x_weight = cx->weight; p.x_taps = ax->host.taps;
-            p.x_per_lane = pl; p.x_step = sx; p.x_groups = cx->groups; p.xw_stride = cx->stride;
-            p.fma = fma;
-            p.y_step_weight = cy->step_weight; p.y_step = sy; p.y_taps = ay->host.taps; p.y_base = cy->base;
-            p.rot = rot;
-            p.dpp = want_dpp ? 1 : 0;
-            p.xcd_remap = opt_xcd == 1 || (opt_xcd == 0 && (pl >= 2 || want_dpp)) ? 1 : 0;
-            const long long col_waves = (cx->groups + 63) / 64;
-            // row chunks: at least ~32 K waves per launch, chunks of >= 16 output rows.  Every chunk re-reads and
-            // re-filters TY - SY halo rows.  The reference arithmetic is VALU-bound and wants few, long chunks; the fma
-            // flavour is memory-bound and gains 3 % from ~40-row chunks when the halo is short (in XCD-contiguous order
-            // the chunks in flight on an XCD then cover a compact piece of the image): profiles/r01_ab_row_chunks.txt
-            long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
-            if (opt_chunks <= 0 && fma && ay->host.taps - sy <= 5) chunks = std::max<long long>(chunks, (d0.height + 39) / 40);
-            chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
-            p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
-            p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
-            int done = 0;
-            while (done < n) {
-                const int m = std::min(n - done, 65535);
-                StreamParams q = p;
-                q.n_images = m;
-                if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
-                else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
-                HIP_TRY(launch_resize_stream_kernel(pixel, q, s, &g_last_kernel));
-                done += m;
-            }
-            if (tab.used) return temp_release(ctx->tables, s);
-            return PICHA_OK;
+            return launch_stream(pl, cx, cy, rot, want_dpp, false, 0, 0);
         }
     }
     // ---- accumulator kernel (no ring): any downscale whose span-kernel ring would be large.  The ring costs
@@ -834,50 +925,76 @@ int convert_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst
     return PICHA_OK;
 }
 
-// per-thread, per-device stream for the host-pointer entry points
-int host_stream(int dev, hipStream_t *out) {
-    thread_local std::map<int, hipStream_t> streams;
-    auto it = streams.find(dev);
-    if (it == streams.end()) {
-        hipStream_t s;
-        HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-        it = streams.emplace(dev, s).first;
-    }
-    *out = it->second;
-    return PICHA_OK;
-}
+// Host-pointer entry points: stream + pinned staging buffer + device arena travel together as one "lane", leased from
+// a bounded per-device pool for the duration of a call.  (They used to be thread_local and were never freed: a service
+// that spawns a thread per request leaked ~50 MB pinned + ~50 MB HBM per dead thread.)  Memory is now bounded by the
+// number of CONCURRENT callers; lanes beyond kMaxIdleLanes are destroyed when they come back.
+struct HostLane {
+    hipStream_t s = nullptr;
+    uint8_t *pinned = nullptr; size_t pinned_cap = 0;
+    uint8_t *arena = nullptr;  size_t arena_cap = 0;
+};
+struct LanePool { std::mutex mu; std::vector<HostLane *> idle; };
+constexpr size_t kMaxIdleLanes = 4;
+std::mutex g_lane_mu;
+std::map<int, LanePool *> g_lane_pools;  // never destroyed: static destruction order vs. the HIP runtime
 
-// per-thread pinned host staging buffer (grow-only)
-int pinned_staging(size_t bytes, uint8_t **out) {
-    struct Buf { uint8_t *p = nullptr; size_t cap = 0; };
-    thread_local Buf b;
-    if (b.cap < bytes) {
-        if (b.p) (void)hipHostFree(b.p);
-        b.p = nullptr; b.cap = 0;
-        size_t cap = align_up(bytes + bytes / 4, 1 << 20);
-        HIP_TRY(hipHostMalloc((void **)&b.p, cap, hipHostMallocDefault));
-        b.cap = cap;
-    }
-    *out = b.p;
-    return PICHA_OK;
+LanePool *lane_pool(int dev) {
+    std::lock_guard<std::mutex> lk(g_lane_mu);
+    auto &p = g_lane_pools[dev];
+    if (!p) p = new LanePool;
+    return p;
 }
-
-// per-thread, per-device arena for the host-pointer entry points (grow-only; only ever used on
-// this thread's own stream, and every call ends with a stream synchronise)
-int device_arena(int dev, size_t bytes, uint8_t **out) {
-    struct Buf { uint8_t *p = nullptr; size_t cap = 0; };
-    thread_local std::map<int, Buf> arenas;
-    Buf &b = arenas[dev];
-    if (b.cap < bytes) {
-        if (b.p) HIP_TRY(hipFree(b.p));
-        b.p = nullptr; b.cap = 0;
-        const size_t cap = align_up(bytes + bytes / 4, 1 << 20);
-        HIP_TRY(hipMalloc((void **)&b.p, cap));
-        b.cap = cap;
-    }
-    *out = b.p;
-    return PICHA_OK;
+void lane_destroy(HostLane *l) {  // errors ignored: also runs at teardown
+    if (l->s) (void)hipStreamDestroy(l->s);
+    if (l->pinned) (void)hipHostFree(l->pinned);
+    if (l->arena) (void)hipFree(l->arena);
+    delete l;
 }
+struct LaneLease {
+    int dev = -1;
+    HostLane *lane = nullptr;
+    ~LaneLease() {
+        if (!lane) return;
+        LanePool *pool = lane_pool(dev);
+        {
+            std::lock_guard<std::mutex> lk(pool->mu);
+            if (pool->idle.size() < kMaxIdleLanes) { pool->idle.push_back(lane); lane = nullptr; }
+        }
+        if (lane) lane_destroy(lane);  // the stream is idle: every call ends with hipStreamSynchronize
+    }
+    int acquire(int device) {
+        dev = device;
+        LanePool *pool = lane_pool(dev);
+        {
+            std::lock_guard<std::mutex> lk(pool->mu);
+            if (!pool->idle.empty()) { lane = pool->idle.back(); pool->idle.pop_back(); }
+        }
+        if (!lane) {
+            lane = new HostLane;
+            hipError_t e = hipStreamCreateWithFlags(&lane->s, hipStreamNonBlocking);
+            if (e != hipSuccess) { delete lane; lane = nullptr; return fail(PICHA_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+        }
+        return PICHA_OK;
+    }
+    int reserve(size_t bytes) {  // grow-only within the lane
+        if (lane->pinned_cap < bytes) {
+            if (lane->pinned) (void)hipHostFree(lane->pinned);
+            lane->pinned = nullptr; lane->pinned_cap = 0;
+            const size_t cap = align_up(bytes + bytes / 4, 1 << 20);
+            HIP_TRY(hipHostMalloc((void **)&lane->pinned, cap, hipHostMallocDefault));
+            lane->pinned_cap = cap;
+        }
+        if (lane->arena_cap < bytes) {
+            if (lane->arena) HIP_TRY(hipFree(lane->arena));
+            lane->arena = nullptr; lane->arena_cap = 0;
+            const size_t cap = align_up(bytes + bytes / 4, 1 << 20);
+            HIP_TRY(hipMalloc((void **)&lane->arena, cap));
+            lane->arena_cap = cap;
+        }
+        return PICHA_OK;
+    }
+};
 
 enum class Op { Resize, Convert, Chain };
 
@@ -897,9 +1014,10 @@ int run_host(Op op, int n, const picha_image *src, const picha_image *dst, int f
     int dev;
     int rc = current_device(&dev);
     if (rc) return rc;
-    hipStream_t s;
-    rc = host_stream(dev, &s);
+    LaneLease lease;
+    rc = lease.acquire(dev);
     if (rc) return rc;
+    hipStream_t s = lease.lane->s;
 
     // one device arena and one pinned host mirror of it: [src images | dst images], 256-byte aligned.
     // Transfers go through the pinned mirror as two 1-D copies (pageable / 2-D async copies are
@@ -909,12 +1027,9 @@ int run_host(Op op, int n, const picha_image *src, const picha_image *dst, int f
     for (int i = 0; i < n; ++i) { soff[i] = total; total += align_up(image_span(src[i]), 256); }
     const size_t dst_begin = total;
     for (int i = 0; i < n; ++i) { doff[i] = total; total += align_up(image_span(dst[i]), 256); }
-    uint8_t *pinned = nullptr;
-    rc = pinned_staging(total + 256, &pinned);
+    rc = lease.reserve(total + 256);
     if (rc) return rc;
-    uint8_t *arena = nullptr;
-    rc = device_arena(dev, total + 256, &arena);
-    if (rc) return rc;
+    uint8_t *pinned = lease.lane->pinned, *arena = lease.lane->arena;
     std::vector<picha_image> dsrc(src, src + n), ddst(dst, dst + n);
     // stage in pieces: while the DMA engine moves one piece, the next one is being copied into the pinned mirror
     // (by a few threads for large pieces, dispatch.cpp) — a 4K image is 33 MB, one memcpy of it takes longer than its H2D
@@ -964,7 +1079,10 @@ extern "C" {
 
 int picha_pixel_bytes(int pixel) { return valid_pixel(pixel) ? kBytes[pixel] : 0; }
 int picha_pixel_channels(int pixel) { return valid_pixel(pixel) ? kChannels[pixel] : 0; }
-int picha_row_stride(int width, int pixel) { return (picha_pixel_bytes(pixel) * width + 3) & ~3; }
+int picha_row_stride(int width, int pixel) {  // NativeImage::row_stride (src/picha.h:214) in 64-bit; 0 when it does not fit an int
+    const long long st = ((long long)picha_pixel_bytes(pixel) * width + 3) & ~3LL;
+    return (width < 0 || st > INT32_MAX) ? 0 : (int)st;
+}
 
 int picha_pixel_from_name(const char *name) {
     if (!name) return PICHA_INVALID_PIXEL;
@@ -1073,6 +1191,9 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "per_lane") == 0) { g_opt_per_lane = value; return PICHA_OK; }
     if (strcmp(key, "stream_rot") == 0) { g_opt_stream_rot = value; return PICHA_OK; }
     if (strcmp(key, "dpp") == 0) { g_opt_dpp = value; return PICHA_OK; }
+    if (strcmp(key, "sym") == 0) { g_opt_sym = value; return PICHA_OK; }
+    if (strcmp(key, "sym_nbuf") == 0) { g_opt_sym_nbuf = value; return PICHA_OK; }
+    if (strcmp(key, "block_waves") == 0) { g_opt_block_waves = value; return PICHA_OK; }
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
     if (strcmp(key, "acc") == 0) { g_opt_acc = value; return PICHA_OK; }
     if (strcmp(key, "async_devices") == 0) { g_opt_async_devices = value; return PICHA_OK; }
@@ -1088,6 +1209,9 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "per_lane") == 0) return g_opt_per_lane;
     if (strcmp(key, "stream_rot") == 0) return g_opt_stream_rot;
     if (strcmp(key, "dpp") == 0) return g_opt_dpp;
+    if (strcmp(key, "sym") == 0) return g_opt_sym;
+    if (strcmp(key, "sym_nbuf") == 0) return g_opt_sym_nbuf;
+    if (strcmp(key, "block_waves") == 0) return g_opt_block_waves;
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
     if (strcmp(key, "acc") == 0) return g_opt_acc;
     if (strcmp(key, "async_devices") == 0) return g_opt_async_devices;

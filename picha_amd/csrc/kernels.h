@@ -131,16 +131,24 @@ struct StreamParams {
     int fma;
     // output row y reads source rows y_step*y + y_base + j, j < y_taps
     const float *y_step_weight;  // [dst_h + (y_taps-1)/y_step][YW]; YW = roundup4(ceil(y_taps/y_step)*y_step + 1);
-                                 // last dword of a record: int flag, 1 = weights identical to the previous record
+                                 // last dword of a record: int flags, bit 0 = weights identical to the previous record, bit 1 = canonical step
     int y_step, y_taps, y_base;
     int rot;  // 1: row-granular variant with rotating accumulators; 0: step-granular, fully unrolled roles
     int xcd_remap;  // 1: permute workgroup ids so each XCD gets a contiguous range of (strip, chunk, image)
     int dpp;  // 1: cross-lane pixel-sharing variant (x tables: per_lane 1, uniform base step*x + L0, L0 == -1)
     int rows_per_chunk, n_chunks;
+    // resize_sym_kernel (kernels_sym.hip): uniform AND symmetric tap tables.  Outputs [cx0, cx1) have the canonical weights
+    // (x_canon[min(j, T-1-j)], float bits) and the window start x_step*x + x_base; the step records of y_step_weight carry
+    // bit 1 in their flag dword when every output row of the step is canonical (weights y_canon[...]).
+    int32_t x_canon[8], y_canon[8];
+    int cx0, cx1, x_base;
+    int nbuf, block_waves;  // row buffers in registers (prefetch depth + 1), waves per workgroup: select the instantiation
 };
 bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot);
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty);
+bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int nbuf, int block_waves);
+hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 
 // ---- Image helpers on device images (lib/image.js:57-73) -------------------------------------------
 struct CompareParams {

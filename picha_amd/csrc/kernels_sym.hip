@@ -1,0 +1,278 @@
+// kernels_sym.hip — streaming resize kernel for integer scale factors whose tap tables are UNIFORM AND SYMMETRIC
+// (every interior output has the same weights w[0..T), and w[j] == w[T-1-j] bit for bit: true for all six picha
+// filters whenever the scale is an integer, src/resize.cc:19-50 — the tap centre then lands on an integer or
+// half-integer position and the filters are even functions of |offset|).
+//
+// What that buys over resize_stream_kernel (same decomposition: a wave owns 64*P adjacent output columns of a row chunk
+// and marches down the source rows; no LDS, no barrier; vertical accumulators in registers; src/resize.cc:99-132):
+//   * the weights are wave-uniform: (T+1)/2 VGPRs per axis instead of P*TX lane-resident ones, which is what makes three
+//     or four outputs per lane affordable (fewer pixel conversions per output: a lane converts S*(P-1)+TX pixels for P
+//     outputs);
+//   * products are SHARED between outputs without moving a rounding: source pixel q is tap j of output o and tap j' of
+//     output o' with w[j] == w[j'] bitwise, so fl(w[j] * u) is computed once and added into both sums — each sum still
+//     adds the reference's products in the reference's (ascending) order.  The same holds vertically: resampled row r
+//     is tap j of output row m and tap j' of row m - i.  The sharing is left to common-subexpression elimination: the
+//     code below just names the weight by its symmetric index min(j, T-1-j).
+// Edge handling: waves that contain an output whose window hangs over the left/right image edge (different, renormalised
+// weights) run the general per-lane-weight horizontal pass; steps that touch an output row at the top/bottom edge
+// run the general vertical fold with that step's own weights.  Both are wave-uniform decisions.
+#define PICHA_SPAN_ONLY 1
+#include "kernels_impl.inc"
+
+namespace picha_hip {
+namespace {
+
+template <int N> using IC = std::integral_constant<int, N>;
+constexpr int ce_min(int a, int b) { return a < b ? a : b; }
+
+// pack + store the P pixels of one lane (whole dwords wherever the layout allows it)
+template <typename C, int CH, bool S16, int P, bool FMA>
+__device__ __forceinline__ void store_lane_outputs(const float (&v)[P][CH], __amdgpu_buffer_rsrc_t dst_rs, uint32_t doff, int x0, int dst_w) {
+    if (x0 + P <= dst_w) {
+        if constexpr (C::WORDS) {
+            constexpr int DPP = C::BPP / 4;
+            uint32_t dw[P * DPP];
+#pragma unroll
+            for (int q = 0; q < P; ++q) {
+                uint32_t t[2];
+                pack_px_words<CH, S16, FMA>(v[q], t);
+                dw[q * DPP] = t[0];
+                if constexpr (DPP == 2) dw[q * DPP + 1] = t[1];
+            }
+            store_dwords<P * DPP, kStoreNT>(dst_rs, doff, dw);
+            return;
+        } else if constexpr ((P * C::BPP) % 4 == 0) {
+            // sub-dword pixels: the lane's P pixels are whole dwords at a 4-byte aligned address (host-checked)
+            constexpr int NDW = P * C::BPP / 4, SPD = S16 ? 2 : 4;
+            float flat[P * CH];
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) flat[q * CH + c] = v[q][c];
+            uint32_t dw[NDW];
+#pragma unroll
+            for (int j = 0; j < NDW; ++j) { uint32_t t2[2]; pack_px_words<SPD, S16, FMA>(&flat[SPD * j], t2); dw[j] = t2[0]; }
+            store_dwords<NDW, kStoreNT>(dst_rs, doff, dw);
+            return;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < P; ++q)
+        if (x0 + q < dst_w) {
+            uint32_t pw[2];
+            pack_px_words<CH, S16, FMA>(v[q], pw);
+            store_px_words<CH, S16, kStoreNT>(dst_rs, doff + q * C::BPP, pw);
+        }
+}
+
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA, int NBUF, int BW>
+__global__ __launch_bounds__(BW * 64) void resize_sym_kernel(StreamParams p) {
+    using C = SpanCfg<CH, S16, P, SX, TX>;
+    constexpr int NPEND = (TY - 1) / SY + 1;
+    constexpr int ICLOSE = (TY - 1) / SY, PHCLOSE = (TY - 1) % SY;
+    constexpr int YW = (NPEND * SY + 1 + 3) / 4 * 4;  // dwords per step record: NPEND*SY weights, flags in the last dword
+    constexpr int TXH = (TX + 1) / 2, TYH = (TY + 1) / 2;
+
+    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.xcd_remap) xcd_contiguous_block(bx, by, bz);
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int grp0 = (bx * BW + wave) * kWave;
+    if (grp0 * P >= p.dst_w) return;  // wave-uniform; the kernel has no barriers
+    const int x0 = (grp0 + lane) * P;
+
+    const int img = bz;
+    const uint8_t *sbase = p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch;
+    uint8_t *dbase = p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch;
+    const int sadj = C::BROT ? int(reinterpret_cast<uintptr_t>(sbase) & 3u) : 0;
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(sbase) - sadj, 0, C::BROT ? ((p.src_bytes + sadj + 3u) & ~3u) : p.src_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
+
+    const int y0 = by * p.rows_per_chunk;
+    const int y1 = min(p.dst_h, y0 + p.rows_per_chunk);
+    if (y0 >= y1) return;
+    const int m_end = y1 - 1 + ICLOSE;  // last step that completes an output row of this chunk
+    const_i32_ptr ystep = (const_i32_ptr)(p.y_step_weight);
+
+    // every output of this wave has the canonical weights and window start SX*x + x_base?
+    const bool interior = grp0 * P >= p.cx0 && (grp0 + kWave) * P <= p.cx1;
+
+    auto march = [&](auto xc_c, auto nb_c) __attribute__((always_inline)) {
+        constexpr bool XC = decltype(xc_c)::value;
+        constexpr int NB = decltype(nb_c)::value;               // row buffers in registers: NB - 1 rows are in flight per wave
+        constexpr int BPER = NB / ce_gcd(NB, SY);                   // steps after which the row-buffer roles repeat
+        constexpr int USTEPS = NPEND * BPER / ce_gcd(NPEND, BPER);  // ... and the accumulator roles too: unrolled together
+        // horizontal weights: canonical (wave-uniform, indexed by symmetric id) or lane-resident (edge waves)
+        float wx[XC ? 1 : P][XC ? TXH : TX];
+        int32_t lane_off;
+        bool neg_lane = false;
+        if constexpr (XC) {
+#pragma unroll
+            for (int id = 0; id < TXH; ++id) asm volatile("v_mov_b32 %0, %1" : "=v"(wx[0][id]) : "s"(p.x_canon[id]));
+            lane_off = (SX * x0 + p.x_base) * C::BPP + sadj;
+        } else {
+            const int grp = min(grp0 + lane, p.x_groups - 1);
+#pragma unroll
+            for (int q = 0; q < P; ++q)
+#pragma unroll
+                for (int j = 0; j < TX; ++j) wx[q][j] = p.x_weight[(size_t)j * p.xw_stride + grp * P + q];
+            lane_off = p.x_left[grp] * C::BPP + sadj;
+            neg_lane = __any(lane_off < 0);
+        }
+        float wyc[TYH];
+#pragma unroll
+        for (int id = 0; id < TYH; ++id) asm volatile("v_mov_b32 %0, %1" : "=v"(wyc[id]) : "s"(p.y_canon[id]));
+
+        float acc[NPEND][P][CH];  // static roles: at step index K of the unrolled group, output m - i lives in slot (i - K) mod NPEND
+        uint32_t raw[NB][C::NW];
+
+        auto load_row = [&](uint32_t (&t)[C::NW], int row) __attribute__((always_inline)) {
+            const int rr = (row >= p.src_h) ? p.src_h : row;  // rows outside the image read 0 (outside the descriptor)
+            const int32_t off = rr * p.src_stride + lane_off;
+            if constexpr (XC) {
+                load_span<C, false>(src_rs, off, t);
+            } else {
+                // a lane whose span starts before the image (left edge): in row 0 a wrapped offset would void the whole
+                // merged load, so that row is fetched dword by dword with clamped offsets (zero-weight taps only)
+                if (neg_lane && rr <= 0) load_span<C, true>(src_rs, off, t);
+                else load_span<C, false>(src_rs, off, t);
+            }
+        };
+
+        auto one_step = [&](int m, auto k_c) __attribute__((always_inline)) {
+            constexpr int K = decltype(k_c)::value;
+            int wb[YW];
+#pragma unroll
+            for (int t = 0; t < YW; ++t) wb[t] = ystep[(size_t)m * YW + t];
+            const bool ycanon = (wb[YW - 1] & 2) != 0;  // all NPEND outputs of this step exist and are canonical
+#pragma unroll
+            for (int ph = 0; ph < SY; ++ph) {
+                const int T = K * SY + ph;                 // row index inside the unrolled group (a constant after unrolling)
+                const int bi = T % NB;                     // buffer holding this row
+                const int bn = (T + NB - 1) % NB;          // buffer consumed by the previous row: refill it, NB-1 rows ahead
+                const int row = SY * m + p.y_base + ph;
+                load_row(raw[bn], row + NB - 1);
+                // ---- horizontal pass (src/resize.cc:110-117) ----
+                float h[P][CH];
+                uint32_t win[C::BROT ? C::NWIN : 1];
+                if constexpr (C::BROT)
+                    rotate_span<C>(raw[bi], uint32_t(((row >= p.src_h) ? p.src_h : row) * p.src_stride + lane_off) & 3u, win);
+#pragma unroll
+                for (int q = 0; q < C::SPAN; ++q) {
+                    float u[CH];
+                    if constexpr (C::BROT) unpack_span_px<C, CH, S16, FMA>(win, q, u);
+                    else unpack_span_px<C, CH, S16, FMA>(raw[bi], q, u);
+#pragma unroll
+                    for (int o = 0; o < P; ++o) {
+                        const int j = q - SX * o;  // tap index of span pixel q for output o
+                        if (j >= 0 && j < TX) {
+                            float w;
+                            if constexpr (XC) w = wx[0][ce_min(j, TX - 1 - j)];
+                            else w = wx[o][j];
+#pragma unroll
+                            for (int c = 0; c < CH; ++c) {
+                                if (j == 0) h[o][c] = w * u[c];
+                                else if constexpr (FMA) h[o][c] = __builtin_fmaf(w, u[c], h[o][c]);
+                                else h[o][c] = h[o][c] + w * u[c];  // identical products (same w bits, same u) are computed once
+                            }
+                        }
+                    }
+                }
+                // ---- fold into the pending outputs (src/resize.cc:125-129, one tap per pending output) ----
+                auto fold = [&](auto yc_c) __attribute__((always_inline)) {
+                    constexpr bool YC = decltype(yc_c)::value;
+#pragma unroll
+                    for (int i = 0; i < NPEND; ++i) {
+                        const int j = SY * i + ph;
+                        if (j < TY) {
+                            const int sl = ((i - K) % NPEND + NPEND) % NPEND;
+                            float w;
+                            if constexpr (YC) w = wyc[ce_min(j, TY - 1 - j)];
+                            else asm volatile("v_mov_b32 %0, %1" : "=v"(w) : "s"(wb[i * SY + ph]));
+#pragma unroll
+                            for (int o = 0; o < P; ++o)
+#pragma unroll
+                                for (int c = 0; c < CH; ++c) {
+                                    if (j == 0) acc[sl][o][c] = w * h[o][c];
+                                    else if constexpr (FMA) acc[sl][o][c] = __builtin_fmaf(w, h[o][c], acc[sl][o][c]);
+                                    else acc[sl][o][c] = acc[sl][o][c] + w * h[o][c];
+                                }
+                        }
+                    }
+                };
+                if (ycanon) fold(std::true_type{});
+                else fold(std::false_type{});
+                if (ph == PHCLOSE) {
+                    const int y = m - ICLOSE;
+                    if (y >= y0) {  // outputs above the chunk belong to the previous chunk
+                        const int sl = ((ICLOSE - K) % NPEND + NPEND) % NPEND;
+                        store_lane_outputs<C, CH, S16, P, FMA>(acc[sl], dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
+                    }
+                }
+            }
+        };
+
+#pragma unroll
+        for (int d = 0; d < NB - 1; ++d) load_row(raw[d], SY * y0 + p.y_base + d);
+        for (int m = y0; m <= m_end; m += USTEPS) {
+            auto run = [&](auto self, auto kc) __attribute__((always_inline)) -> void {
+                constexpr int k = decltype(kc)::value;
+                if constexpr (k < USTEPS) {
+                    if (k == 0 || m + k <= m_end) {
+                        one_step(m + k, IC<k>{});
+                        self(self, IC<k + 1>{});
+                    }
+                }
+            };
+            run(run, IC<0>{});
+        }
+    };
+    // edge waves carry P*TX lane-resident weights: they give up one row of prefetch so that the kernel's register
+    // allocation (the maximum over both versions) is set by the interior version
+    if (interior) march(std::true_type{}, IC<NBUF>{});
+    else march(std::false_type{}, IC<(NBUF > 2 ? NBUF - 1 : 2)>{});
+}
+
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, int NBUF, int BW>
+hipError_t launch_sym_t(const StreamParams &p, hipStream_t s, const char **name) {
+    dim3 grid((p.x_groups + 64 * BW - 1) / (64 * BW), p.n_chunks, p.n_images);
+    if (p.fma) resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true, NBUF, BW><<<grid, 64 * BW, 0, s>>>(p);
+    else resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false, NBUF, BW><<<grid, 64 * BW, 0, s>>>(p);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_sym<ch%d,%s,P%d,SX%d,TX%d,SY%d,TY%d,%s,nbuf%d,bw%d>", CH, S16 ? "u16" : "u8", P,
+             SX, TX, SY, TY, p.fma ? "fma" : "exact", NBUF, BW);
+    if (name) *name = g_kernel_name;
+    return hipGetLastError();
+}
+
+// X(pixel, channels, 16-bit, P, SX, TX, SY, TY, NBUF, BW)
+#define PICHA_SYM_LIST(X) \
+    X(1, 4, false, 2, 2, 5, 2, 5, 3, 4) X(1, 4, false, 3, 2, 5, 2, 5, 3, 4) X(1, 4, false, 4, 2, 5, 2, 5, 3, 4) \
+    X(1, 4, false, 2, 2, 5, 2, 5, 4, 4) X(1, 4, false, 3, 2, 5, 2, 5, 4, 4) X(1, 4, false, 4, 2, 5, 2, 5, 4, 4) \
+    X(1, 4, false, 3, 2, 5, 2, 5, 3, 2) X(1, 4, false, 3, 2, 5, 2, 5, 3, 10) X(1, 4, false, 4, 2, 5, 2, 5, 3, 8) \
+    X(1, 4, false, 2, 2, 5, 2, 5, 3, 15) X(1, 4, false, 3, 2, 5, 2, 5, 3, 5) X(1, 4, false, 3, 2, 5, 2, 5, 3, 1) \
+    X(1, 4, false, 2, 2, 5, 2, 5, 3, 1) X(1, 4, false, 2, 2, 5, 2, 5, 3, 2) X(1, 4, false, 4, 2, 5, 2, 5, 3, 1) X(1, 4, false, 4, 2, 5, 2, 5, 3, 2) \
+    X(1, 4, false, 2, 2, 5, 2, 5, 4, 1) X(1, 4, false, 3, 2, 5, 2, 5, 4, 1) X(1, 4, false, 3, 2, 5, 2, 5, 4, 2) X(1, 4, false, 2, 2, 5, 2, 5, 2, 1) \
+    X(1, 4, false, 3, 2, 5, 2, 5, 2, 1) X(1, 4, false, 3, 2, 5, 2, 5, 5, 1) X(1, 4, false, 2, 2, 5, 2, 5, 5, 1) X(1, 4, false, 2, 2, 5, 2, 5, 6, 1)
+
+}  // namespace
+
+bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int nbuf, int bw) {
+#define X(PX, CH, S16, P, SX, TX, SY, TY, NBUF, BW) \
+    if (pixel == PX && per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY && nbuf == NBUF && bw == BW) return true;
+    PICHA_SYM_LIST(X)
+#undef X
+    return false;
+}
+
+hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **name) {
+#define X(PX, CH, S16, P, SX, TX, SY, TY, NBUF, BW)                                                                              \
+    if (pixel == PX && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY && p.nbuf == NBUF && \
+        p.block_waves == BW)                                                                                                     \
+        return launch_sym_t<CH, S16, P, SX, TX, SY, TY, NBUF, BW>(p, s, name);
+    PICHA_SYM_LIST(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace picha_hip

@@ -116,6 +116,10 @@ static napi_value new_js_image(napi_env env, int w, int h, int pixel, picha_imag
     napi_value obj, v, buf;
     void *p = NULL;
     int stride = picha_row_stride(w, pixel);
+    if (stride <= 0 || w <= 0 || h <= 0) { /* width * bytes-per-pixel does not fit an int stride (the reference wraps) */
+        napi_throw_error(env, NULL, "invalid dimensions");
+        return NULL;
+    }
     NAPI_OK(napi_create_object(env, &obj));
     NAPI_OK(napi_create_int32(env, w, &v));
     NAPI_OK(napi_set_named_property(env, obj, "width", v));
