@@ -78,8 +78,8 @@ long g_opt_acc = 0;         // accumulator kernel: 0 auto (when the span kernel'
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 long g_opt_stream_rot = 0;  // 0 auto, 1 force the rotating-accumulator streaming variant, 2 force the unrolled one
 long g_opt_dpp = 0;         // 0 auto, 1 prefer / 2 forbid the cross-lane pixel-sharing streaming kernel
+long g_opt_cc_mode = 0;     // colour convert: 0 auto (wide kernel when rows are dword aligned), 1 always the 4-pixel kernel, 2 wide + nt stores
 long g_opt_sym = 0;         // symmetric-table streaming kernel (kernels_sym.hip): 0 auto (when available), 2 never
-long g_opt_sym_nbuf = 0;    // its row buffers in registers (0 auto)
 long g_opt_block_waves = 0; // its waves per workgroup (0 auto)
 
 // ---- per-device state ---------------------------------------------------------------------------
@@ -572,6 +572,25 @@ int make_tables(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, 
     return PICHA_OK;
 }
 
+// Outputs per lane for which resize_sym_kernel beats the general streaming / accumulator kernels by >= 2 % (0: it does not):
+// interleaved survey of all 8 formats x {2x: 3, 5, 7 taps; 3x: 8, 12; 4x: 11, 15} on 64 x 4K images, both numerics flavours
+// (scripts/survey_sym.py, profiles/r02_survey_sym_exact.txt, r02_survey_sym_fma.txt).
+int sym_preferred_per_lane(int pixel, int step, int taps, int fma) {
+    struct E { int8_t step, taps, exact, fma; };
+    static const E rgb[] = {{2, 5, 0, 4}, {3, 8, 4, 0}, {4, 11, 0, 4}, {4, 15, 0, 4}, {0, 0, 0, 0}};
+    static const E rgba[] = {{2, 5, 3, 2}, {2, 7, 0, 2}, {3, 8, 2, 2}, {4, 11, 2, 2}, {4, 15, 0, 2}, {0, 0, 0, 0}};
+    static const E grey[] = {{2, 5, 0, 4}, {2, 7, 0, 4}, {0, 0, 0, 0}};
+    static const E greya[] = {{2, 3, 0, 2}, {2, 5, 0, 4}, {2, 7, 0, 4}, {3, 8, 2, 2}, {3, 12, 2, 0}, {0, 0, 0, 0}};
+    static const E r16[] = {{2, 3, 4, 2}, {2, 5, 4, 4}, {2, 7, 4, 4}, {3, 8, 2, 2}, {3, 12, 2, 2}, {4, 11, 2, 2}, {0, 0, 0, 0}};
+    static const E r16g16[] = {{2, 3, 2, 2}, {2, 5, 4, 2}, {2, 7, 3, 4}, {3, 12, 0, 2}, {4, 15, 0, 2}, {0, 0, 0, 0}};
+    static const E r16g16b16[] = {{2, 3, 2, 2}, {2, 5, 2, 2}, {2, 7, 2, 2}, {3, 12, 0, 2}, {0, 0, 0, 0}};
+    static const E *const tabs[8] = {rgb, rgba, grey, greya, r16, r16g16, r16g16b16, r16g16b16 /* r16g16b16a16: same picks */};
+    if (pixel < 0 || pixel > 7) return 0;
+    for (const E *e = tabs[pixel]; e->step; ++e)
+        if (e->step == step && e->taps == taps) return fma ? e->fma : e->exact;
+    return 0;
+}
+
 // ---- resize of one equal-geometry group on device ------------------------------------------------
 int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, int filter,
                  float fscale, hipStream_t s) {
@@ -584,10 +603,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (rc) return rc;
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
-    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_sym_nbuf, opt_bw;
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_bw;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
-        opt_sym = g_opt_sym; opt_sym_nbuf = g_opt_sym_nbuf; opt_bw = g_opt_block_waves;
+        opt_sym = g_opt_sym; opt_bw = g_opt_block_waves;
         opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
         opt_rot = g_opt_stream_rot;
         opt_dpp = g_opt_dpp;
@@ -645,8 +664,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         // coalesced loads, but measured 2-4 % SLOWER than the plain variant on cfg2 (the kernel is bound by
         // mixed read/write HBM traffic, not by the conversions it saves): opt-in only ("dpp" = 1)
         // fills the parameters, sizes the row chunks and launches (resize_stream_kernel family or resize_sym_kernel)
-        auto launch_stream = [&](int pl, const DeviceAxis::XTable *cx, const DeviceAxis::YStream *cy, int rot, bool dpp, bool sym, int nbuf,
-                                 int bw) -> int {
+        auto launch_stream = [&](int pl, const DeviceAxis::XTable *cx, const DeviceAxis::YStream *cy, int rot, bool dpp, bool sym, int bw) -> int {
             StreamParams p{};
             long long sp = 0, dp = 0;
             TablePair tab;
@@ -675,7 +693,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 memcpy(p.x_canon, cx->canon, sizeof p.x_canon);
                 memcpy(p.y_canon, cy->canon, sizeof p.y_canon);
                 p.cx0 = cx->c0; p.cx1 = cx->c1; p.x_base = cx->xbase;
-                p.nbuf = nbuf; p.block_waves = bw;
+                p.block_waves = bw;
             }
             const long long col_waves = (cx->groups + 63) / 64;
             // row chunks: at least ~32 K waves per launch, chunks of >= 16 output rows.  Every chunk re-reads and
@@ -684,6 +702,14 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             // the chunks in flight on an XCD then cover a compact piece of the image): profiles/r01_ab_row_chunks.txt
             long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + n * col_waves - 1) / (n * col_waves);
             if (opt_chunks <= 0 && fma && ay->host.taps - sy <= 5) chunks = std::max<long long>(chunks, (d0.height + 39) / 40);
+            if (opt_chunks <= 0 && sym) {
+                // resize_sym_kernel (r02, profiles/r02_ab_sym_*.txt): waves that live for ~60 output rows (reference arithmetic)
+                // or ~20 (fma flavour, memory-bound) keep the chip's working set compact and its tail short; the TY - SY halo
+                // rows a chunk re-filters cost less than that gains while the halo stays under ~8 % of the chunk
+                const int halo = std::max(0, ay->host.taps - sy);
+                const int rows = std::max(fma ? 20 : 60, (halo * 12 + sy - 1) / sy);
+                chunks = std::max<long long>(chunks, (d0.height + rows - 1) / rows);
+            }
             chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
             p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
             p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
@@ -703,13 +729,14 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         // symmetric uniform tables (every picha filter at an integer scale): wave-uniform weights, products shared between
         // outputs (kernels_sym.hip).  Needs at least one interior wave to pay.
         if (opt_sym != 2 && opt_dpp != 1 && opt_rot == 0) {
-            const int cand_sym[] = {3, 4, 2, 1};
+            // outputs per lane: the measured best for this (format, scale, taps, flavour), or what "per_lane" forces
+            const int pref = sym_preferred_per_lane(pixel, sx, ax->host.taps, fma);
+            const int cand_sym[5] = {opt_per_lane > 0 ? (int)opt_per_lane : pref, 0, 0, 0, 0};
             for (int pl : cand_sym) {
+                if (pl == 0) break;
                 if (opt_per_lane > 0 && pl != opt_per_lane) continue;
                 if (subdword && ((pl * kBytes[pixel]) % 4 != 0 || !dst_dword_rows)) continue;
-                const int nb = opt_sym_nbuf > 0 ? (int)opt_sym_nbuf : 3;
-                const int bw = opt_bw > 0 ? (int)opt_bw : 2;
-                if (!sym_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps, nb, bw)) continue;
+                if (!sym_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps)) continue;
                 const DeviceAxis::XTable *cx = nullptr;
                 const DeviceAxis::YStream *cy = nullptr;
                 rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, xw_mode, is16, &cx);
@@ -717,8 +744,11 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 rc = get_ystream(ctx, ay, sy, ay->host.taps, &cy);
                 if (rc) return rc;
                 if (!cx->ok || !cy->ok || !cx->sym || !cy->sym) continue;
-                if (cx->c1 - cx->c0 < 2 * 64 * pl) continue;
-                return launch_stream(pl, cx, cy, 0, false, true, nb, bw);
+                if (cx->c1 - cx->c0 < 2 * 64 * pl) continue;  // needs interior waves to pay
+                // waves per workgroup: small groups backfill the SIMDs sooner (reference arithmetic: VALU + latency bound,
+                // -3..5 %); the memory-bound fma flavour prefers 4 (neighbouring strips share their edge lines in one L1)
+                const int bw = opt_bw > 0 ? (int)std::min<long>(opt_bw, 4) : (fma ? 4 : 2);
+                return launch_stream(pl, cx, cy, 0, false, true, bw);
             }
         }
         bool want_dpp = opt_dpp == 1 && stream_dpp_supported(pixel, sx, ax->host.taps, sy, ay->host.taps);
@@ -756,7 +786,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 if (rot < 0) continue;
             }
             if (!cx->ok || !cy->ok) continue;
-            return launch_stream(pl, cx, cy, rot, want_dpp, false, 0, 0);
+            return launch_stream(pl, cx, cy, rot, want_dpp, false, 0);
         }
     }
     // ---- accumulator kernel (no ring): any downscale whose span-kernel ring would be large.  The ring costs
@@ -911,6 +941,14 @@ int convert_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst
     p.src_stride = s0.stride; p.dst_stride = d0.stride;
     p.width = s0.width; p.height = s0.height;
     p.r = r; p.g = g; p.b = b;
+    {   // the wide (16-byte access) kernel needs dword-aligned rows on both sides and 32-bit offsets inside an image
+        const size_t sspan = image_span(s0), dspan = image_span(d0);
+        bool wide = sspan < (1ull << 32) - 64 && dspan < (1ull << 32) - 64;
+        for (int i = 0; i < n && wide; ++i)
+            if ((((uintptr_t)src[i].data | (uintptr_t)src[i].stride | (uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) & 3) != 0) wide = false;
+        p.wide_ok = wide ? 1 : 0;
+        p.src_bytes = (unsigned)sspan; p.dst_bytes = (unsigned)dspan;
+    }
     int done = 0;
     while (done < n) {
         const int m = std::min(n - done, 65535);
@@ -1192,7 +1230,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "stream_rot") == 0) { g_opt_stream_rot = value; return PICHA_OK; }
     if (strcmp(key, "dpp") == 0) { g_opt_dpp = value; return PICHA_OK; }
     if (strcmp(key, "sym") == 0) { g_opt_sym = value; return PICHA_OK; }
-    if (strcmp(key, "sym_nbuf") == 0) { g_opt_sym_nbuf = value; return PICHA_OK; }
+    if (strcmp(key, "cc_mode") == 0) { g_opt_cc_mode = value; set_color_convert_mode((int)value); return PICHA_OK; }
     if (strcmp(key, "block_waves") == 0) { g_opt_block_waves = value; return PICHA_OK; }
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
     if (strcmp(key, "acc") == 0) { g_opt_acc = value; return PICHA_OK; }
@@ -1210,7 +1248,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "stream_rot") == 0) return g_opt_stream_rot;
     if (strcmp(key, "dpp") == 0) return g_opt_dpp;
     if (strcmp(key, "sym") == 0) return g_opt_sym;
-    if (strcmp(key, "sym_nbuf") == 0) return g_opt_sym_nbuf;
+    if (strcmp(key, "cc_mode") == 0) return g_opt_cc_mode;
     if (strcmp(key, "block_waves") == 0) return g_opt_block_waves;
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
     if (strcmp(key, "acc") == 0) return g_opt_acc;

@@ -20,7 +20,12 @@ struct ConvertParams {
     int width, height;
     int n_images;
     float r, g, b;
+    // wide kernel (16 / 8 pixels per thread, 16-byte accesses): every image base and both strides are 4-byte aligned and
+    // one image spans less than 4 GB; src_bytes / dst_bytes = bytes of ONE image (buffer descriptor range)
+    int wide_ok;
+    unsigned src_bytes, dst_bytes;
 };
+void set_color_convert_mode(int mode);  // 0 auto, 1 always the 4-pixel kernel, 2 wide kernel with non-temporal stores
 // src_pixel != dst_pixel.  Returns hipSuccess or the launch error.
 hipError_t launch_color_convert(int src_pixel, int dst_pixel, const ConvertParams &p, hipStream_t s);
 
@@ -142,12 +147,12 @@ struct StreamParams {
     // bit 1 in their flag dword when every output row of the step is canonical (weights y_canon[...]).
     int32_t x_canon[8], y_canon[8];
     int cx0, cx1, x_base;
-    int nbuf, block_waves;  // row buffers in registers (prefetch depth + 1), waves per workgroup: select the instantiation
+    int block_waves;  // waves per workgroup (1..4)
 };
 bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot);
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty);
-bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int nbuf, int block_waves);
+bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty);
 hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 
 // ---- Image helpers on device images (lib/image.js:57-73) -------------------------------------------

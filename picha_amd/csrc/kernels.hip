@@ -22,6 +22,30 @@ PICHA_DECL_STREAM(0) PICHA_DECL_STREAM(1) PICHA_DECL_STREAM(2) PICHA_DECL_STREAM
 PICHA_DECL_STREAM(4) PICHA_DECL_STREAM(5) PICHA_DECL_STREAM(6) PICHA_DECL_STREAM(7)
 #undef PICHA_DECL_STREAM
 
+// defined in kernels_sym.hip, one translation unit per pixel format
+#define PICHA_DECL_SYM(N)                                                                \
+    bool sym_supported_pixel##N(int per_lane, int sx, int tx, int sy, int ty);            \
+    hipError_t launch_sym_pixel##N(const StreamParams &p, hipStream_t s, const char **name);
+PICHA_DECL_SYM(0) PICHA_DECL_SYM(1) PICHA_DECL_SYM(2) PICHA_DECL_SYM(3)
+PICHA_DECL_SYM(4) PICHA_DECL_SYM(5) PICHA_DECL_SYM(6) PICHA_DECL_SYM(7)
+#undef PICHA_DECL_SYM
+bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return sym_supported_pixel##N(per_lane, sx, tx, sy, ty);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return false;
+}
+hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **name) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return launch_sym_pixel##N(p, s, name);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
 bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot) {
     switch (pixel) {
 #define PICHA_CASE(N) case N: return stream_supported_pixel##N(per_lane, sx, tx, sy, ty, rot);
@@ -47,6 +71,7 @@ bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty) {
 // ---------------------------------------------------------------------------------------------
 // Launch interface
 // ---------------------------------------------------------------------------------------------
+void set_color_convert_mode(int mode) { g_cc_mode = mode; }
 hipError_t launch_color_convert(int sp, int dp, const ConvertParams &p, hipStream_t s) {
     switch (sp) {
     case 0: return launch_cc_src<0>(dp, p, s);

@@ -65,9 +65,13 @@ __device__ __forceinline__ void store_lane_outputs(const float (&v)[P][CH], __am
         }
 }
 
-template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA, int NBUF, int BW>
-__global__ __launch_bounds__(BW * 64) void resize_sym_kernel(StreamParams p) {
+// NBUF row buffers in registers (NBUF - 1 rows in flight per wave): 3 unless a row is more than 12 dwords per lane
+template <int CH, bool S16, int P, int SX, int TX> constexpr int sym_nbuf() { return SpanCfg<CH, S16, P, SX, TX>::NW <= 12 ? 3 : 2; }
+
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA>
+__global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
     using C = SpanCfg<CH, S16, P, SX, TX>;
+    constexpr int NBUF = sym_nbuf<CH, S16, P, SX, TX>();
     constexpr int NPEND = (TY - 1) / SY + 1;
     constexpr int ICLOSE = (TY - 1) / SY, PHCLOSE = (TY - 1) % SY;
     constexpr int YW = (NPEND * SY + 1 + 3) / 4 * 4;  // dwords per step record: NPEND*SY weights, flags in the last dword
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(BW * 64) void resize_sym_kernel(StreamParams p) {
     if (p.xcd_remap) xcd_contiguous_block(bx, by, bz);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int grp0 = (bx * BW + wave) * kWave;
+    const int grp0 = (bx * (blockDim.x >> 6) + wave) * kWave;  // 1..4 waves per workgroup (host's choice)
     if (grp0 * P >= p.dst_w) return;  // wave-uniform; the kernel has no barriers
     const int x0 = (grp0 + lane) * P;
 
@@ -234,42 +238,56 @@ __global__ __launch_bounds__(BW * 64) void resize_sym_kernel(StreamParams p) {
     else march(std::false_type{}, IC<(NBUF > 2 ? NBUF - 1 : 2)>{});
 }
 
-template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, int NBUF, int BW>
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY>
 hipError_t launch_sym_t(const StreamParams &p, hipStream_t s, const char **name) {
-    dim3 grid((p.x_groups + 64 * BW - 1) / (64 * BW), p.n_chunks, p.n_images);
-    if (p.fma) resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true, NBUF, BW><<<grid, 64 * BW, 0, s>>>(p);
-    else resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false, NBUF, BW><<<grid, 64 * BW, 0, s>>>(p);
-    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_sym<ch%d,%s,P%d,SX%d,TX%d,SY%d,TY%d,%s,nbuf%d,bw%d>", CH, S16 ? "u16" : "u8", P,
-             SX, TX, SY, TY, p.fma ? "fma" : "exact", NBUF, BW);
+    const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 2;
+    dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
+    if (p.fma) resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true><<<grid, 64 * bw, 0, s>>>(p);
+    else resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false><<<grid, 64 * bw, 0, s>>>(p);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_sym<ch%d,%s,P%d,SX%d,TX%d,SY%d,TY%d,%s,bw%d>", CH, S16 ? "u16" : "u8", P, SX, TX, SY,
+             TY, p.fma ? "fma" : "exact", bw);
     if (name) *name = g_kernel_name;
     return hipGetLastError();
 }
 
-// X(pixel, channels, 16-bit, P, SX, TX, SY, TY, NBUF, BW)
-#define PICHA_SYM_LIST(X) \
-    X(1, 4, false, 2, 2, 5, 2, 5, 3, 4) X(1, 4, false, 3, 2, 5, 2, 5, 3, 4) X(1, 4, false, 4, 2, 5, 2, 5, 3, 4) \
-    X(1, 4, false, 2, 2, 5, 2, 5, 4, 4) X(1, 4, false, 3, 2, 5, 2, 5, 4, 4) X(1, 4, false, 4, 2, 5, 2, 5, 4, 4) \
-    X(1, 4, false, 3, 2, 5, 2, 5, 3, 2) X(1, 4, false, 3, 2, 5, 2, 5, 3, 10) X(1, 4, false, 4, 2, 5, 2, 5, 3, 8) \
-    X(1, 4, false, 2, 2, 5, 2, 5, 3, 15) X(1, 4, false, 3, 2, 5, 2, 5, 3, 5) X(1, 4, false, 3, 2, 5, 2, 5, 3, 1) \
-    X(1, 4, false, 2, 2, 5, 2, 5, 3, 1) X(1, 4, false, 2, 2, 5, 2, 5, 3, 2) X(1, 4, false, 4, 2, 5, 2, 5, 3, 1) X(1, 4, false, 4, 2, 5, 2, 5, 3, 2) \
-    X(1, 4, false, 2, 2, 5, 2, 5, 4, 1) X(1, 4, false, 3, 2, 5, 2, 5, 4, 1) X(1, 4, false, 3, 2, 5, 2, 5, 4, 2) X(1, 4, false, 2, 2, 5, 2, 5, 2, 1) \
-    X(1, 4, false, 3, 2, 5, 2, 5, 2, 1) X(1, 4, false, 3, 2, 5, 2, 5, 5, 1) X(1, 4, false, 2, 2, 5, 2, 5, 5, 1) X(1, 4, false, 2, 2, 5, 2, 5, 6, 1)
+// Instantiations per pixel format: X(P, SX, TX, SY, TY) — the (format, scale, tap count, outputs per lane) combinations that
+// beat the general streaming / accumulator kernels in either numerics flavour (r02 survey of all 8 formats x 7 integer-scale
+// cases, profiles/r02_survey_sym_{exact,fma}.txt; the planner's preference table is sym_preferred_per_lane in capi.cpp),
+// plus rgba at 2x with 2..4 outputs per lane for the parity tests.  Tap counts of picha's filters at integer scales (all
+// symmetric): 2x: 3 (triangle), 5 (default options), 7 (cubic / mitchel / catmulrom); 3x: 8, 12; 4x: 11, 15.  lanczos and
+// box at even integer scales alias the reference's ring (src/resize.cc:52-64) and stay on the span kernel.
+#define PICHA_SYM_LIST_0(X) /* rgb */ X(4, 2, 5, 2, 5) X(4, 3, 8, 3, 8) X(4, 4, 11, 4, 11) X(4, 4, 15, 4, 15)
+#define PICHA_SYM_LIST_1(X) /* rgba */ X(2, 2, 5, 2, 5) X(3, 2, 5, 2, 5) X(4, 2, 5, 2, 5) X(2, 2, 7, 2, 7) X(3, 2, 7, 2, 7) \
+    X(2, 3, 8, 3, 8) X(2, 4, 11, 4, 11) X(2, 4, 15, 4, 15)
+#define PICHA_SYM_LIST_2(X) /* grey */ X(4, 2, 5, 2, 5) X(4, 2, 7, 2, 7)
+#define PICHA_SYM_LIST_3(X) /* greya */ X(2, 2, 3, 2, 3) X(4, 2, 5, 2, 5) X(4, 2, 7, 2, 7) X(2, 3, 8, 3, 8) X(2, 3, 12, 3, 12)
+#define PICHA_SYM_LIST_4(X) /* r16 */ X(2, 2, 3, 2, 3) X(4, 2, 3, 2, 3) X(4, 2, 5, 2, 5) X(4, 2, 7, 2, 7) X(2, 3, 8, 3, 8) \
+    X(2, 3, 12, 3, 12) X(2, 4, 11, 4, 11)
+#define PICHA_SYM_LIST_5(X) /* r16g16 */ X(2, 2, 3, 2, 3) X(2, 2, 5, 2, 5) X(4, 2, 5, 2, 5) X(3, 2, 7, 2, 7) X(4, 2, 7, 2, 7) \
+    X(2, 3, 12, 3, 12) X(2, 4, 15, 4, 15)
+#define PICHA_SYM_LIST_6(X) /* r16g16b16 */ X(2, 2, 3, 2, 3) X(2, 2, 5, 2, 5) X(2, 2, 7, 2, 7) X(2, 3, 12, 3, 12)
+#define PICHA_SYM_LIST_7(X) /* r16g16b16a16 */ X(2, 2, 3, 2, 3) X(2, 2, 5, 2, 5) X(2, 2, 7, 2, 7) X(2, 3, 12, 3, 12)
 
 }  // namespace
 
-bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int nbuf, int bw) {
-#define X(PX, CH, S16, P, SX, TX, SY, TY, NBUF, BW) \
-    if (pixel == PX && per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY && nbuf == NBUF && bw == BW) return true;
+#ifndef PICHA_SYM_PIXEL
+#error "compile with -DPICHA_SYM_PIXEL=0..7"
+#endif
+#define PICHA_CAT2(a, b) a##b
+#define PICHA_CAT(a, b) PICHA_CAT2(a, b)
+#define PICHA_SYM_LIST PICHA_CAT(PICHA_SYM_LIST_, PICHA_SYM_PIXEL)
+
+bool PICHA_CAT(sym_supported_pixel, PICHA_SYM_PIXEL)(int per_lane, int sx, int tx, int sy, int ty) {
+#define X(P, SX, TX, SY, TY) if (per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY) return true;
     PICHA_SYM_LIST(X)
 #undef X
     return false;
 }
 
-hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **name) {
-#define X(PX, CH, S16, P, SX, TX, SY, TY, NBUF, BW)                                                                              \
-    if (pixel == PX && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY && p.nbuf == NBUF && \
-        p.block_waves == BW)                                                                                                     \
-        return launch_sym_t<CH, S16, P, SX, TX, SY, TY, NBUF, BW>(p, s, name);
+hipError_t PICHA_CAT(launch_sym_pixel, PICHA_SYM_PIXEL)(const StreamParams &p, hipStream_t s, const char **name) {
+#define X(P, SX, TX, SY, TY)                                                                                          \
+    if (p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY)                     \
+        return launch_sym_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY>(p, s, name);
     PICHA_SYM_LIST(X)
 #undef X
     return hipErrorInvalidValue;

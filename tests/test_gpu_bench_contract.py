@@ -45,4 +45,4 @@ def test_bench_other_workloads_run():
         assert d["value"] > 0 and d["roofline"]["frac"] > 0
     d = _run("--workload", "custom", "--shape", "4:rgb:640:480:320:240", "--steps", "2", "--warmup", "1", "--prewarm-ms", "0",
              "--no-cpu-baseline")
-    assert "resize_stream<ch3" in d["config"]["kernel"]
+    assert "resize_sym<ch3" in d["config"]["kernel"] or "resize_stream<ch3" in d["config"]["kernel"]

@@ -23,7 +23,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "sym", "block_waves"):
         set_opt(k, 0)
 
 
@@ -172,7 +172,7 @@ def test_full_size_subdword_2x_streaming_equals_span_kernel_and_oracle(pixel):
     out = resize_batch(src, 1920, 1080)
     torch.cuda.synchronize()
     name = N.lib().picha_hip_last_kernel().decode()
-    assert name.startswith("resize_stream") and ",P4," in name, name
+    assert (name.startswith("resize_sym") or name.startswith("resize_stream")) and (",P4," in name or ",P2," in name), name
     set_opt("path", 3)
     ref = resize_batch(src, 1920, 1080)
     torch.cuda.synchronize()

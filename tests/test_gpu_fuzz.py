@@ -17,12 +17,16 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode"):
         set_opt(k, 0)
 
 
 def _sizes(rng):
-    kind = rng.integers(0, 9)
+    kind = rng.integers(0, 10)
+    if kind == 9:    # exact integer decimation, wide enough for interior waves of the symmetric-table kernel (several outputs per lane)
+        f = int(rng.choice([2, 2, 2, 3, 4]))
+        dw, dh = int(rng.integers(260, 1100)), int(rng.integers(3, 40))
+        return dw * f, dh * f, dw, dh
     if kind == 8:    # very strong horizontal downscale: windows of 37 .. 128+ taps (long-window accumulator kernel, two-pass)
         dw, dh = int(rng.integers(1, 40)), int(rng.integers(1, 30))
         return dw * int(rng.integers(13, 44)) + int(rng.integers(0, 9)), dh * int(rng.integers(1, 9)) + int(rng.integers(0, 4)), dw, dh
@@ -84,7 +88,9 @@ def test_random_resizes_match_oracle(seed):
         numerics = int(rng.integers(0, 4) == 0)
         set_opt("path", path)
         set_opt("numerics", numerics)
-        set_opt("per_lane", int(rng.choice([0, 0, 1, 2, 4])))
+        set_opt("per_lane", int(rng.choice([0, 0, 0, 1, 2, 3, 4])))
+        set_opt("sym", int(rng.choice([0, 0, 2])))
+        set_opt("block_waves", int(rng.choice([0, 0, 1, 2, 4])))
         set_opt("row_chunks", int(rng.choice([0, 0, 1, 2, 7])))
         set_opt("stream_rot", int(rng.choice([0, 1, 2])))
         set_opt("xcd_remap", int(rng.choice([0, 1, 2])))
@@ -119,6 +125,7 @@ def test_random_color_converts_match_oracle():
             r, g, b = (float(v) for v in rng.uniform(0.05, 2.0, size=3))
             opts.update(redWeight=r, greenWeight=g, blueWeight=b)
             wts = picha_amd.color_settings(r, g, b)
+        set_opt("cc_mode", int(rng.choice([0, 0, 1, 2])))
         got = picha_amd.colorConvertSync(img, opts)
         exp = oracle_convert(img, dp, weights=wts)
         assert np.array_equal(payload(got), payload(exp)), (w, h, sp, dp, opts)

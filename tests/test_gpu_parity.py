@@ -33,6 +33,9 @@ def _reset_path():
     set_opt("row_chunks", 0)
     set_opt("stream_rot", 0)
     set_opt("dpp", 0)
+    set_opt("sym", 0)
+    set_opt("block_waves", 0)
+    set_opt("cc_mode", 0)
 
 
 def test_device_is_gfx950():
@@ -204,26 +207,37 @@ def test_resize_async_equals_sync():
 
 
 # ---- multi-output lanes (uniform integer scale), row chunking, and the fma numerics flavour ------------
-@pytest.mark.parametrize("per_lane", [1, 2, 4])
+@pytest.mark.parametrize("per_lane", [1, 2, 3, 4])
 def test_resize_rgba_2x_multi_output_lanes(per_lane):
-    """cfg2's structure at small size: rgba, exact 2x down, default cubic (5 taps) — every lane layout
-    of the fused kernel must be bit-identical to the oracle, including edges and a ragged last group."""
+    """cfg2's structure at small size: rgba, exact 2x down, default cubic (5 taps) — every lane layout of every fused
+    kernel family must be bit-identical to the oracle, including edges, a ragged last group and images too narrow for an
+    interior wave (the symmetric-table kernel then hands over to the general streaming kernel)."""
     rng = np.random.default_rng(40 + per_lane)
-    for (sw, sh) in [(640, 480), (262, 98), (18, 10), (1030, 36)]:
+    for (sw, sh) in [(640, 480), (262, 98), (18, 10), (1030, 36), (2600, 24)]:
         img = rand_image(rng, sw, sh, "rgba")
         exp = oracle_resize(img, sw // 2, sh // 2, "cubic", 0.70)
         exp7 = oracle_resize(img, sw // 2, sh // 2, "cubic", 1.0)
         for chunks in (0, 1, 3):
-            for path, family in ((2, "resize_stream"), (3, "resize_span")):  # streaming (no LDS) and LDS-ring kernels
+            # symmetric-table streaming kernel, general streaming kernel (no LDS), LDS-ring kernel
+            for path, sym, family in ((2, 0, "resize_sym"), (2, 2, "resize_stream"), (3, 0, "resize_span")):
+                if per_lane == 3 and family != "resize_sym":
+                    continue  # three outputs per lane exist only in the symmetric-table kernel
                 set_path(path)
+                set_opt("sym", sym)
                 set_opt("per_lane", per_lane)
                 set_opt("row_chunks", chunks)
-                got = picha_amd.resizeSync(img, {"width": sw // 2, "height": sh // 2})
-                name = N.lib().picha_hip_last_kernel().decode()
-                assert name.startswith(family), name
-                assert "P%d" % per_lane in name, name
-                assert max_code_diff(got, exp) == 0, (sw, sh, per_lane, chunks, name)
-                if per_lane <= 2:  # 7-tap variant ({filter: 'cubic'} resets filterScale to 1.0)
+                for bw in ((0, 1, 4) if family == "resize_sym" else (0,)):
+                    set_opt("block_waves", bw)
+                    got = picha_amd.resizeSync(img, {"width": sw // 2, "height": sh // 2})
+                    name = N.lib().picha_hip_last_kernel().decode()
+                    # the symmetric-table kernel needs two interior waves (2 * 64 * per_lane canonical outputs) and has no
+                    # one-output-per-lane instantiation for rgba at 2x
+                    want = family if not (family == "resize_sym" and (per_lane == 1 or sw // 2 < 2 * 64 * per_lane + 2)) else "resize_stream"
+                    assert name.startswith(want), (name, sw, per_lane)
+                    assert "P%d" % per_lane in name, name
+                    assert max_code_diff(got, exp) == 0, (sw, sh, per_lane, chunks, name)
+                set_opt("block_waves", 0)
+                if per_lane <= 3:  # 7-tap variant ({filter: 'cubic'} resets filterScale to 1.0)
                     got = picha_amd.resizeSync(img, {"width": sw // 2, "height": sh // 2, "filter": "cubic"})
                     name = N.lib().picha_hip_last_kernel().decode()
                     assert max_code_diff(got, exp7) == 0, (sw, sh, per_lane, chunks, name)
@@ -238,7 +252,7 @@ def test_resize_fma_numerics_streaming_kernel():
         set_opt("per_lane", per_lane)
         got = picha_amd.resizeSync(img, {"width": 320, "height": 240})
         name = N.lib().picha_hip_last_kernel().decode()
-        assert name.startswith("resize_stream") and "fma" in name, name
+        assert (name.startswith("resize_stream") or name.startswith("resize_sym")) and "fma" in name, name
         assert max_code_diff(got, exp) <= 1, name
 
 
@@ -332,7 +346,7 @@ def test_resize_16bit_streaming_kernel_rotating_accumulators():
             set_opt("row_chunks", chunks)
             got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
             name = N.lib().picha_hip_last_kernel().decode()
-            assert name.startswith("resize_stream") and "rot" in name, name
+            assert name.startswith("resize_sym") or (name.startswith("resize_stream") and "rot" in name), name
             exp = oracle_resize(img, dw, dh, opts.get("filter", "cubic"), 1.0 if "filter" in opts else 0.70)
             assert max_code_diff(got, exp) == 0, (sw, sh, opts, chunks, name)
         set_opt("numerics", 1)
@@ -399,7 +413,8 @@ def test_resize_subdword_multi_output_streaming_kernel(pixel):
                 set_opt("row_chunks", chunks)
                 got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
                 name = N.lib().picha_hip_last_kernel().decode()
-                streamed += name.startswith("resize_stream<ch%d" % N.PIXEL_CHANNELS[pixel]) and ",P1," not in name
+                streamed += (name.startswith("resize_stream<ch%d" % N.PIXEL_CHANNELS[pixel]) or
+                             name.startswith("resize_sym<ch%d" % N.PIXEL_CHANNELS[pixel])) and ",P1," not in name
                 assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, chunks, name)
             set_opt("row_chunks", 0)
             set_opt("numerics", 1)
@@ -421,7 +436,7 @@ def test_resize_subdword_multi_output_streaming_kernel(pixel):
     resize_batch(src, out=odd)
     torch.cuda.synchronize()
     name = N.lib().picha_hip_last_kernel().decode()
-    assert not name.startswith("resize_stream"), name
+    assert not name.startswith("resize_stream") and not name.startswith("resize_sym"), name
     for i in range(2):
         exp = oracle_resize(src.image_host(i), 128, 48)
         assert np.array_equal(payload(odd.image_host(i)), payload(exp)), (pixel, i, name)
@@ -432,7 +447,11 @@ def test_kernel_selection_for_the_baseline_workloads():
     to the two-pass kernels is a 10x performance regression that parity tests alone do not see)."""
     rng = np.random.default_rng(7)
     cases = [
-        ("rgba", 384, 216, 192, 108, {}, "resize_stream<ch4,u8,P2,SX2,TX5,SY2,TY5"),                     # cfg2
+        ("rgba", 384, 216, 192, 108, {}, "resize_stream<ch4,u8,P2,SX2,TX5,SY2,TY5"),                     # cfg2 geometry, too narrow for interior waves
+        ("rgba", 1920, 108, 960, 54, {}, "resize_sym<ch4,u8,P3,SX2,TX5,SY2,TY5"),                        # cfg2: symmetric-table kernel
+        ("r16g16b16a16", 1536, 64, 768, 32, {}, "resize_sym<ch4,u16,P2,SX2,TX5,SY2,TY5"),
+        ("r16", 2048, 64, 1024, 32, {"filter": "triangle"}, "resize_sym<ch1,u16,P4,SX2,TX3,SY2,TY3"),
+        ("greya", 2304, 96, 768, 32, {}, "resize_sym<ch2,u8,P2,SX3,TX8,SY3,TY8"),
         ("rgba", 384, 216, 192, 108, {"filter": "cubic"}, "resize_stream<ch4,u8,P2,SX2,TX7,SY2,TY7"),     # cfg2, 7 taps
         ("grey", 3840, 216, 512, 51, {"filter": "lanczos"}, "resize_acc<ch1,u8,TX36,NACC6"),              # cfg3b (x: 7.5x, y: 4.2x)
         ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_acc<ch4,u16,TX16,NACC4"),              # cfg5
