@@ -183,6 +183,9 @@ int picha_hip_color_convert_async(const picha_image *src, const picha_image *dst
 int picha_hip_async_drain(void);
 /* Number of batches the dispatcher has launched and of requests it has completed (diagnostics). */
 void picha_hip_async_stats(uint64_t *batches, uint64_t *requests);
+/* The same for the index-th dispatcher (one per device the "async_devices" option spreads requests over); returns the number
+ * of dispatchers that exist.  Replaces nothing in the reference (its libuv pool has no per-worker statistics). */
+int picha_hip_async_dispatcher_stats(int index, uint64_t *batches, uint64_t *requests);
 
 /* ---- the hot path: device-resident entry points ------------------------------------------------
  * Same operations on images whose `data` already lives in the current device's HBM.  Asynchronous:

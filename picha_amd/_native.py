@@ -66,6 +66,7 @@ SYMBOLS = [
     ("picha_hip_color_convert_async", _i, [_P, _P, _f, _f, _f, _vp, _vp]),
     ("picha_hip_async_drain", _i, []),
     ("picha_hip_async_stats", None, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
+    ("picha_hip_async_dispatcher_stats", _i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     ("picha_hip_resize_device", _i, [_i, _P, _P, _i, _f, _vp]),
     ("picha_hip_color_convert_device", _i, [_i, _P, _P, _f, _f, _f, _vp]),
     ("picha_hip_convert_resize_device", _i, [_i, _P, _P, _i, _f, _f, _f, _i, _f, _vp]),

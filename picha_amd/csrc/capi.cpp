@@ -74,6 +74,7 @@ long g_opt_async_devices = [] {
     const char *e = getenv("PICHA_HIP_ASYNC_DEVICES");
     return e ? std::max(0L, atol(e)) : 0L;
 }();
+long g_opt_async_virtual = 0;  // 1: "async_devices" may exceed the visible device count (dispatcher k runs on device k mod visible)
 long g_opt_acc = 0;         // accumulator kernel: 0 auto (when the span kernel's ring would be large), 1 whenever representable, 2 never
 long g_opt_per_lane = 0;    // 0 auto, else outputs per lane for the fused kernel (1, 2, 4)
 long g_opt_stream_rot = 0;  // 0 auto, 1 force the rotating-accumulator streaming variant, 2 force the unrolled one
@@ -1235,6 +1236,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
     if (strcmp(key, "acc") == 0) { g_opt_acc = value; return PICHA_OK; }
     if (strcmp(key, "async_devices") == 0) { g_opt_async_devices = value; return PICHA_OK; }
+    if (strcmp(key, "async_virtual_devices") == 0) { g_opt_async_virtual = value; return PICHA_OK; }
     if (strcmp(key, "chain_window_mb") == 0) { g_opt_chain_window_mb = value; return PICHA_OK; }
     return fail(PICHA_ERR_ARGUMENT, "unknown option %s", key);
 }
@@ -1253,6 +1255,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
     if (strcmp(key, "acc") == 0) return g_opt_acc;
     if (strcmp(key, "async_devices") == 0) return g_opt_async_devices;
+    if (strcmp(key, "async_virtual_devices") == 0) return g_opt_async_virtual;
     if (strcmp(key, "chain_window_mb") == 0) return g_opt_chain_window_mb;
     return -1;
 }

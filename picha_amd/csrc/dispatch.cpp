@@ -136,6 +136,7 @@ struct Slot {
 
 class Dispatcher {
 public:
+    // `device` is the physical HIP device; several dispatchers may share one (option "async_virtual_devices")
     explicit Dispatcher(int device) : device_(device) {
         stager_ = std::thread([this] { stage_loop(); });
         completer_ = std::thread([this] { complete_loop(); });
@@ -311,10 +312,10 @@ private:
 std::mutex g_mu;
 std::map<int, std::unique_ptr<Dispatcher>> g_disp;
 
-Dispatcher *dispatcher_for(int dev) {
+Dispatcher *dispatcher_for(int slot, int physical_device) {
     std::lock_guard<std::mutex> lk(g_mu);
-    auto &p = g_disp[dev];
-    if (!p) p.reset(new Dispatcher(dev));
+    auto &p = g_disp[slot];
+    if (!p) p.reset(new Dispatcher(physical_device));
     return p.get();
 }
 
@@ -330,12 +331,19 @@ int submit(int kind, int order, const picha_image *src, const picha_image *dst, 
     // "async_devices" = N > 0: requests are dealt round-robin to devices 0 .. min(N, visible) - 1, each with its own
     // dispatcher (stager, completer, streams, staging): one host process feeds every GPU of the node with independent
     // images, no exchange between devices.  Default (0): the caller's current device only.
+    // "async_virtual_devices" = 1 lets N exceed the visible device count: dispatcher k then runs on physical device
+    // k mod visible — on a one-GPU box this exercises the spread itself (several dispatchers, each with its own streams
+    // and staging, fed round-robin) although they share the card.
     const long want = picha_hip_get_option("async_devices");
+    int slot = dev;  // dispatcher index; physical device = slot mod visible
+    int phys = dev;
     if (want > 0) {
         static std::atomic<unsigned> next{0};
         int ndev = 1;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
-        dev = (int)(next.fetch_add(1) % (unsigned)std::min<long>(want, ndev));
+        const long n = picha_hip_get_option("async_virtual_devices") > 0 ? want : std::min<long>(want, ndev);
+        slot = (int)(next.fetch_add(1) % (unsigned)n);
+        phys = slot % ndev;
     }
     Request q;
     q.kind = kind;
@@ -347,7 +355,7 @@ int submit(int kind, int order, const picha_image *src, const picha_image *dst, 
     q.r = r; q.g = g; q.b = b;
     q.done = done;
     q.user = user;
-    dispatcher_for(dev)->enqueue(q);
+    dispatcher_for(slot, phys)->enqueue(q);
     return PICHA_OK;
 }
 
@@ -382,6 +390,19 @@ int picha_hip_async_drain(void) {
     }
     for (Dispatcher *d : all) d->drain();
     return PICHA_OK;
+}
+
+int picha_hip_async_dispatcher_stats(int index, uint64_t *batches, uint64_t *requests) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    int i = 0;
+    for (auto &kv : g_disp) {
+        if (i++ == index) {
+            if (batches) *batches = kv.second->batches;
+            if (requests) *requests = kv.second->completed;
+            break;
+        }
+    }
+    return (int)g_disp.size();
 }
 
 void picha_hip_async_stats(uint64_t *batches, uint64_t *requests) {

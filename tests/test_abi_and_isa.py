@@ -118,7 +118,7 @@ def test_reference_arithmetic_kernels_have_no_fused_multiply_add(device_disassem
             re.search(r"resize_acc(?:_long)?_kernelI.*ELb([01])EEEvNS_", name) or \
             re.search(r"resize_stream_kernelI.*ELb([01])ELb[01]EEEvNS_", name) or \
             re.search(r"resize_stream_dpp_kernelI.*ELb([01])EEEvNS_", name) or \
-            re.search(r"resize_sym_kernelI.*ELb([01])ELi\d+ELi\d+EEEvNS_", name)  # <..., FMA, NBUF, BW>
+            re.search(r"resize_sym_kernelI.*ELb([01])EEEvNS_", name)  # <..., FMA>
         if m and m.group(1) == "1":
             fma_flavour += 1
             assert body["fused"], "fma flavour without fma? " + name

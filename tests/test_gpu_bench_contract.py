@@ -46,3 +46,28 @@ def test_bench_other_workloads_run():
     d = _run("--workload", "custom", "--shape", "4:rgb:640:480:320:240", "--steps", "2", "--warmup", "1", "--prewarm-ms", "0",
              "--no-cpu-baseline")
     assert "resize_sym<ch3" in d["config"]["kernel"] or "resize_stream<ch3" in d["config"]["kernel"]
+
+
+def test_bench_two_ranks_over_gloo_on_one_gpu():
+    """The N > 1 path of bench.py itself: two ranks launched by torch.distributed.run (before any GPU call), gloo instead
+    of RCCL because both ranks share the one GPU of this box.  Image sharding, the barrier-bracketed timed region
+    (picha_amd.shard.timed_region), the max over ranks and rank 0's JSON line all execute."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PICHA_BENCH_BACKEND="gloo", MASTER_ADDR="127.0.0.1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--images", "8", "--steps", "3",
+                          "--warmup", "1", "--prewarm-ms", "5", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout   # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "image-sharded x2"
+    assert d["config"]["images_per_gpu"] == 8
+    # whole-job value: both ranks' images over the max-over-ranks time
+    assert abs(d["value"] - 2 * 8 * 3840 * 2160 * 3 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 0.01
+    assert d["config"]["parity_max_code_diff_vs_oracle_image0"] == 0

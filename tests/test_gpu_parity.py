@@ -233,8 +233,9 @@ def test_resize_rgba_2x_multi_output_lanes(per_lane):
                     # the symmetric-table kernel needs two interior waves (2 * 64 * per_lane canonical outputs) and has no
                     # one-output-per-lane instantiation for rgba at 2x
                     want = family if not (family == "resize_sym" and (per_lane == 1 or sw // 2 < 2 * 64 * per_lane + 2)) else "resize_stream"
-                    assert name.startswith(want), (name, sw, per_lane)
-                    assert "P%d" % per_lane in name, name
+                    if not (per_lane == 3 and want != "resize_sym"):  # no other family has three outputs per lane: any kernel may serve
+                        assert name.startswith(want), (name, sw, per_lane)
+                        assert "P%d" % per_lane in name, name
                     assert max_code_diff(got, exp) == 0, (sw, sh, per_lane, chunks, name)
                 set_opt("block_waves", 0)
                 if per_lane <= 3:  # 7-tap variant ({filter: 'cubic'} resets filterScale to 1.0)
@@ -319,6 +320,95 @@ def test_async_dispatcher_batches_mixed_requests_and_matches_sync():
         assert err is None
         sync = (picha_amd.resizeSync if kind == "resize" else picha_amd.colorConvertSync)(img, opts)
         assert sync.equalPixels(out), (kind, opts)
+
+
+def test_async_devices_round_robin_over_virtual_devices():
+    """`async_devices` = 2 deals requests round-robin to two dispatchers, each with its own stager, streams and staging.
+    A one-GPU box has one physical device, so `async_virtual_devices` lets both dispatchers share it: the spread itself
+    (routing, independent completion, per-dispatcher statistics) is what runs here."""
+    import threading
+    rng = np.random.default_rng(2718)
+    picha_amd.drain()
+    set_opt("async_virtual_devices", 1)
+    set_opt("async_devices", 2)
+    try:
+        jobs = [rand_image(rng, 96 + 8 * (i % 3), 40, "rgba") for i in range(40)]
+        results = [None] * len(jobs)
+        done = threading.Semaphore(0)
+
+        def make_cb(k):
+            def cb(err, out):
+                results[k] = (err, out)
+                done.release()
+            return cb
+
+        def stats():
+            out = []
+            b, r = ctypes.c_uint64(), ctypes.c_uint64()
+            n = N.lib().picha_hip_async_dispatcher_stats(0, ctypes.byref(b), ctypes.byref(r))
+            for i in range(n):
+                N.lib().picha_hip_async_dispatcher_stats(i, ctypes.byref(b), ctypes.byref(r))
+                out.append(r.value)
+            return out
+
+        before = stats()
+        for k, img in enumerate(jobs):
+            picha_amd.resize(img, {"width": img.width // 2, "height": 20}, make_cb(k))
+        for _ in jobs:
+            assert done.acquire(timeout=120)
+        picha_amd.drain()
+        after = stats()
+        assert len(after) >= 2
+        grew = [a - (before[i] if i < len(before) else 0) for i, a in enumerate(after)]
+        assert sum(grew) == len(jobs)
+        assert sorted(grew)[-2:] == [len(jobs) // 2, len(jobs) // 2], grew   # two dispatchers, half of the requests each
+        for img, (err, out) in zip(jobs, results):
+            assert err is None
+            assert picha_amd.resizeSync(img, {"width": img.width // 2, "height": 20}).equalPixels(out)
+    finally:
+        set_opt("async_devices", 0)
+        set_opt("async_virtual_devices", 0)
+
+
+def test_host_entry_points_do_not_leak_per_thread_resources():
+    """Every synchronous call leases its stream, pinned staging buffer and device arena from a bounded per-device pool
+    (they used to be thread_local and were never freed): many short-lived threads must not grow device memory."""
+    import threading
+    import torch
+    rng = np.random.default_rng(5)
+    img = rand_image(rng, 1024, 512, "rgba")   # 2 MB in, 0.5 MB out: a lane holds ~3 MB pinned + ~3 MB of HBM
+    exp = oracle_resize(img, 512, 256, "cubic", 0.70)
+
+    def work():
+        got = picha_amd.resizeSync(img, {"width": 512, "height": 256})
+        assert max_code_diff(got, exp) == 0
+
+    def burst(n):
+        ts = [threading.Thread(target=work) for _ in range(n)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    burst(8)  # fills the pool (at most 4 idle lanes are kept)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(12):
+        burst(8)   # 96 more threads, each dies after one call
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 16 << 20, (free0, free1)   # thread_local lanes would have leaked ~300 MB here
+
+
+def test_dimensions_whose_row_does_not_fit_an_int_are_refused():
+    """The reference's int row_stride wraps for width * bytes-per-pixel >= 2^31 (src/picha.h:214) and then writes past a
+    too-small buffer; this build refuses the call instead."""
+    img = rand_image(np.random.default_rng(3), 8, 8, "rgba")
+    with pytest.raises(picha_amd.PichaError) as e:
+        picha_amd.resizeSync(img, {"width": 1 << 30, "height": 1})
+    assert "invalid dimensions" in str(e.value)
+    assert N.lib().picha_row_stride(1 << 30, N.pixel_index("rgba")) == 0
+    assert N.lib().picha_row_stride(1920, N.pixel_index("rgba")) == 7680
 
 
 def test_async_argument_errors_are_synchronous():
