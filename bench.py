@@ -37,6 +37,14 @@ WORKLOADS = {
     # intermediate is materialised slice by slice
     "cfg3_4k_rgb_to_grey_to_512_lanczos_chained": (256, 3840, 2160, "rgb", 512, 512, {"convert": "grey", "filter": "lanczos", "chain": True}),
     "cc_4k_rgba_to_rgba16": (64, 3840, 2160, "rgba", 3840, 2160, {"convert": "r16g16b16a16"}),
+    # codec-edge pairs (reference index.js:37-72 supportedMap x the codecs' `encodes` lists, README.md:158-159,
+    # src/pngcodec.cc:61-86): what toSupported() converts before a jpeg / webp encode and what decoders hand to resize
+    "edge_jpeg_4k_rgba_to_rgb": (128, 3840, 2160, "rgba", 3840, 2160, {"convert": "rgb"}),              # tiff/png/webp decode -> jpeg encode
+    "edge_jpeg_4k_rgba16_to_rgb": (64, 3840, 2160, "r16g16b16a16", 3840, 2160, {"convert": "rgb"}),      # deep png -> jpeg
+    "edge_webp_4k_grey_to_rgb": (128, 3840, 2160, "grey", 3840, 2160, {"convert": "rgb"}),               # grey jpeg -> webp
+    "edge_png_4k_rgba16_to_rgba": (64, 3840, 2160, "r16g16b16a16", 3840, 2160, {"convert": "rgba"}),     # deep png -> 8 bit
+    "edge_jpeg_thumb_4k_rgb_to_512x288": (192, 3840, 2160, "rgb", 512, 288, {}),                         # jpeg -> thumbnail -> jpeg
+    "edge_jpeg_4k_rgb_to_1080p": (192, 3840, 2160, "rgb", 1920, 1080, {}),                               # jpeg -> 1080p -> jpeg
     "cfg5_8k_rgba16_to_1080p_mitchel": (32, 7680, 4320, "r16g16b16a16", 1920, 1080, {"filter": "mitchel"}),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable copy)

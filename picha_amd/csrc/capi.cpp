@@ -103,6 +103,7 @@ struct DeviceAxis {
         bool sym = false;
         int c0 = 0, c1 = 0, xbase = 0;
         int32_t canon[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // float bits of w[0 .. (taps+1)/2) in this table's weight flavour
+        std::vector<int32_t> host_left;               // host copy of left[] (row-staged kernel: strip extents)
     };
     std::map<std::tuple<int, int, int, int, int>, XTable> xtables;
     // streaming kernel, y role: uniform-stride view of the table, built on demand per (step, taps)
@@ -123,6 +124,14 @@ struct DeviceAxis {
         int32_t *range = nullptr;  // [dst][2]: first source row needed by this or any later output, last row so far
     };
     std::map<int, YRows> yrows;
+    // row-staged kernel, x role: per column strip of 256 threads the first source pixel staged into LDS
+    struct RowsStrips {
+        bool ok = false;
+        void *blob = nullptr;
+        int32_t *strip_left = nullptr;
+        int n_strips = 0, pieces = 0;  // stage pieces per thread and row (1, 2, 4, 8)
+    };
+    std::map<std::tuple<const void *, int, int>, RowsStrips> rows_strips;
 
     DeviceAxis() = default;
     DeviceAxis(const DeviceAxis &) = delete;
@@ -132,6 +141,7 @@ struct DeviceAxis {
         for (auto &kv : xtables) if (kv.second.blob) (void)hipFree(kv.second.blob);
         for (auto &kv : ystreams) if (kv.second.blob) (void)hipFree(kv.second.blob);
         for (auto &kv : yrows) if (kv.second.blob) (void)hipFree(kv.second.blob);
+        for (auto &kv : rows_strips) if (kv.second.blob) (void)hipFree(kv.second.blob);
     }
     // fused, y role
     int4 *y_info = nullptr;
@@ -143,9 +153,15 @@ struct DeviceAxis {
 using AxisKey = std::tuple<int, uint32_t, int, int>;
 
 // A reusable device (+ optional pinned host) buffer whose successive uses are ordered by an event:
-// the next user, on whatever stream, waits for the previous use to finish.  hipMallocAsync is
-// deliberately not used anywhere: on this stack (ROCm 7.2, gfx950) kernels that read or wrote
-// freshly pool-allocated memory intermittently saw stale data.
+// the next user, on whatever stream, waits for the previous use to finish.  Stream discipline of the
+// library (what tests/test_gpu_parity.py::test_temporaries_are_ordered_across_streams pins): a
+// temporary is only touched by work enqueued between temp_acquire and temp_release on the caller's
+// stream; temp_release records the event on that stream; the next temp_acquire, from any stream,
+// makes its stream wait for the event (or the host, when the pinned half is rewritten).
+// hipMallocAsync is not used: grow-only buffers need no per-call allocation.  (Round 1 blamed a
+// first-session failure — 8 of 192 conversions wrong — on stale pool memory; the record of it,
+// every pair with an 8-byte destination pixel wrong from the first pixel on, is what a kernel bug
+// of that uncommitted code looks like, not what stale memory looks like: the claim is withdrawn.)
 struct TempBuf {
     void *dev = nullptr;
     size_t dev_cap = 0;
@@ -304,9 +320,9 @@ int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, std::sh
 // kernel's buffer loads return 0).  fma = 1: weights pre-multiplied by 1/max of the sample type; fma = 2: the
 // reference's weights times 2^22 for kernels that unpack samples as scaled denormals (kernels_impl.inc, Sample::kDen).
 int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps, int fma, int is16,
-               const DeviceAxis::XTable **out, int bytespan_bpp = 0, bool uniform_base = false) {
+               const DeviceAxis::XTable **out, int bytespan_bpp = 0, bool uniform_base = false, int window_align = 0) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    auto key = std::make_tuple(per_lane, step, taps, fma, is16 + 16 * bytespan_bpp + (uniform_base ? 4096 : 0));
+    auto key = std::make_tuple(per_lane, step, taps, fma, is16 + 16 * bytespan_bpp + (uniform_base ? 4096 : 0) + 65536 * window_align);
     auto it = ax->xtables.find(key);
     if (it != ax->xtables.end()) { *out = &it->second; return PICHA_OK; }
     DeviceAxis::XTable xt;
@@ -323,7 +339,9 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
     // their weights move to the back (zero weights in front leave the sum unchanged)
     // ... and they start on a 4-byte boundary of the row (byte-unaligned dwordx4 loads run at a fraction of
     // the aligned rate): the window start is rounded down to `align_px` pixels, the weights move back by as much
-    const int align_px = bytespan_bpp ? ((bytespan_bpp % 2) ? 4 : 2) : 1;
+    // window_align (row-staged kernel): window starts are multiples of that many pixels (8-byte LDS reads); such windows may
+    // start before pixel 0 and end past the row (the staged span covers them; those taps have weight 0)
+    const int align_px = window_align > 0 ? window_align : bytespan_bpp ? ((bytespan_bpp % 2) ? 4 : 2) : 1;
     int max_left = bytespan_bpp ? t.src_size - taps : INT32_MAX;
     if (bytespan_bpp) max_left -= ((max_left % align_px) + align_px) % align_px;
     if (bytespan_bpp && max_left < 0) ok = false;
@@ -337,7 +355,7 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
         for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) base = std::min(base, t.left[g * per_lane + q] - step * q);
         if (uniform_base) base = step * g * per_lane + l0;
         base = std::min(base, max_left);
-        if (bytespan_bpp) base -= base % align_px;
+        if (bytespan_bpp || window_align > 1) base -= ((base % align_px) + align_px) % align_px;
         left[g] = uniform_base ? l0 : base;
         for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) {
             const int i = g * per_lane + q;
@@ -382,6 +400,7 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
         xt.weight = reinterpret_cast<float *>(static_cast<uint8_t *>(xt.blob) + lb);
         xt.groups = groups;
         xt.stride = stride;
+        xt.host_left = left;
     }
     auto ins = ax->xtables.emplace(key, xt);
     *out = &ins.first->second;
@@ -592,11 +611,197 @@ int sym_preferred_per_lane(int pixel, int step, int taps, int fma) {
     return 0;
 }
 
+// Column strips of the row-staged kernel: strip b = groups [256 b, 256 b + 256); it stages the source pixels from
+// strip_left[b] (a multiple of `piece_px`, possibly negative) up to the end of its last window, `pieces` x 256 x piece_px
+// pixels per row.
+int get_rows_strips(DeviceCtx *ctx, DeviceAxis *ax, const DeviceAxis::XTable *xt, int span_px, int piece_px,
+                    const DeviceAxis::RowsStrips **out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto key = std::make_tuple((const void *)xt, span_px, piece_px);
+    auto it = ax->rows_strips.find(key);
+    if (it != ax->rows_strips.end()) { *out = &it->second; return PICHA_OK; }
+    DeviceAxis::RowsStrips rs;
+    const int groups = xt->groups;
+    const int n_strips = (groups + 255) / 256;
+    std::vector<int32_t> sl(n_strips);
+    int pieces = 1;
+    for (int b = 0; b < n_strips; ++b) {
+        int lo = INT32_MAX, hi = INT32_MIN;
+        for (int g = b * 256; g < std::min(groups, b * 256 + 256); ++g) {
+            lo = std::min(lo, xt->host_left[g]);
+            hi = std::max(hi, xt->host_left[g] + span_px);
+        }
+        lo -= ((lo % piece_px) + piece_px) % piece_px;  // floor to a stage piece
+        sl[b] = lo;
+        const int need = (hi - lo + 1 + 256 * piece_px - 1) / (256 * piece_px);  // +1: an odd span reads one float past its end
+        while (pieces < need) pieces *= 2;
+    }
+    pieces = std::max(pieces, 2);  // instantiated: 2, 4, 8
+    rs.ok = pieces <= 8;
+    rs.n_strips = n_strips;
+    rs.pieces = pieces;
+    if (rs.ok) {
+        HIP_TRY(hipMalloc(&rs.blob, sizeof(int32_t) * n_strips));
+        HIP_TRY(hipMemcpy(rs.blob, sl.data(), sizeof(int32_t) * n_strips, hipMemcpyHostToDevice));
+        rs.strip_left = static_cast<int32_t *>(rs.blob);
+    }
+    auto ins = ax->rows_strips.emplace(key, rs);
+    *out = &ins.first->second;
+    return PICHA_OK;
+}
+
+long g_opt_fuse = 0;  // chained convert+resize: 0 auto (one fused kernel where it exists), 2 always two kernels
+long g_opt_rows = 0;  // row-staged (LDS) downscale kernel: 0 auto, 1 whenever it applies, 2 never
+
+// Row-staged kernel for one equal-geometry group (kernels_rows.hip): plain downscale (src.pixel == dst.pixel) or colour
+// convert fused in front (src.pixel != dst.pixel: the result equals colorConvert followed by resize, the intermediate
+// quantised in registers).  *used = false: not applicable, the caller goes on with the other kernels.
+int rows_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, int filter, float fscale, float r, float g,
+               float b, hipStream_t s, bool *used) {
+    *used = false;
+    const picha_image &s0 = src[0], &d0 = dst[0];
+    const int variant = rows_variant(s0.pixel, d0.pixel);
+    long opt_rows, opt_numerics, opt_chunks, opt_per_lane;
+    {
+        std::lock_guard<std::mutex> lk(g_opt_mu);
+        opt_rows = g_opt_rows; opt_numerics = g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
+    }
+    if (variant < 0 || opt_rows == 2) return PICHA_OK;
+    if (d0.width >= s0.width || d0.height >= s0.height) return PICHA_OK;  // downscales only
+    const size_t src_span = image_span(s0), dst_span = image_span(d0);
+    if (src_span >= (1u << 31) || dst_span >= (1u << 31)) return PICHA_OK;
+    const int dal = fused_align(d0.pixel);
+    for (int i = 0; i < n; ++i) {
+        if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % 4) return PICHA_OK;  // dword loads of whole stage pieces
+        if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % dal) return PICHA_OK;
+    }
+    std::shared_ptr<DeviceAxis> ax_ref, ay_ref;
+    int rc = get_axis(ctx, filter, fscale, s0.width, d0.width, &ax_ref);
+    if (rc) return rc;
+    rc = get_axis(ctx, filter, fscale, s0.height, d0.height, &ay_ref);
+    if (rc) return rc;
+    DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
+    const int taps = ax->host.taps;
+    // where it pays (r02 survey): windows long enough that the per-lane conversions of the accumulator kernel dominate,
+    // or the fused colour convert (whose conversion chain must not be repeated per tap)
+    const bool conv = s0.pixel != d0.pixel;
+    // plain downscales (r02, profiles/r02_ab_rows_*.txt): the kernel is LDS-bound — single-channel formats with two outputs per
+    // thread and >= 26 taps gain 11-13 % over the accumulator kernel (cfg3b), shorter windows and 4-channel pixels lose
+    const bool plain_auto = !conv && opt_rows == 0;
+    if (plain_auto && (taps < 26 || kChannels[d0.pixel] > 2)) return PICHA_OK;
+    const int fma = opt_numerics == 1 ? 1 : 0;
+    const int is16 = d0.pixel >= PICHA_R16;
+    const int align = rows_window_align(variant);
+    const int piece_px = rows_stage_pixels(variant);
+    // shape: two adjacent outputs per thread where the table has a uniform stride (window of the second output S pixels
+    // after the first, zero-padded taps), else one
+    const DeviceAxis::YRows *yr = nullptr;
+    int nacc = 0;
+    for (int na : {4, 6}) {
+        const DeviceAxis::YRows *cand = nullptr;
+        rc = get_yrows(ctx, ay, na, &cand);
+        if (rc) return rc;
+        if (cand->ok) { yr = cand; nacc = na; break; }
+    }
+    if (!yr) return PICHA_OK;
+    // candidates, best first: two adjacent outputs per thread at the table's integer step with the smallest tap bucket
+    // that holds it, then one output per thread; the first whose table, strips and LDS footprint work is taken
+    struct Shape { int per_lane, step, taps; };
+    std::vector<Shape> shapes;
+    const int st = (int)std::floor((double)s0.width / d0.width);
+    static const int p2[][2] = {{3, 12}, {3, 16}, {4, 16}, {4, 20}, {5, 20}, {5, 24}, {6, 24}, {6, 28}, {7, 24}, {7, 32}};
+    if (opt_per_lane != 1)
+        for (auto &e : p2)
+            if (e[0] == st) shapes.push_back({2, e[0], e[1]});
+    if (opt_per_lane != 2 && !plain_auto)   // (one output per thread does not beat the accumulator kernel on plain downscales)
+        for (int tb : {16, 24, 32, 40})
+            if (taps + align - 1 <= tb) { shapes.push_back({1, 1, tb}); break; }
+    const int chl = kChannels[d0.pixel] == 3 ? 4 : kChannels[d0.pixel];
+    const DeviceAxis::XTable *xt = nullptr;
+    const DeviceAxis::RowsStrips *rs = nullptr;
+    int per_lane = 0, step = 1, ktaps = 0;
+    for (const Shape &sh : shapes) {
+        if (!rows_kernel_supported(variant, sh.per_lane, sh.step, sh.taps)) continue;
+        const DeviceAxis::XTable *cx = nullptr;
+        rc = get_xtable(ctx, ax, sh.per_lane, sh.step, sh.taps, fma, is16, &cx, 0, false, align);
+        if (rc) return rc;
+        if (!cx->ok) continue;
+        const DeviceAxis::RowsStrips *cs = nullptr;
+        rc = get_rows_strips(ctx, ax, cx, sh.step * (sh.per_lane - 1) + sh.taps, piece_px, &cs);
+        if (rc) return rc;
+        if (!cs->ok) continue;
+        if ((size_t)2 * cs->pieces * 256 * piece_px * chl * 4 + 16 > 96 * 1024) continue;  // LDS: keep >= 1 workgroup per SIMD pair
+        xt = cx; rs = cs; per_lane = sh.per_lane; step = sh.step; ktaps = sh.taps;
+        break;
+    }
+    if (!xt) return PICHA_OK;
+
+    RowsParams p{};
+    long long sp = 0, dp = 0;
+    TablePair tab;
+    std::unique_lock<std::mutex> temp_lock(ctx->temp_mu, std::defer_lock);
+    if (uniform_pitch(src, n, &sp) && uniform_pitch(dst, n, &dp)) {
+        p.src = static_cast<const uint8_t *>(s0.data);
+        p.dst = static_cast<uint8_t *>(d0.data);
+        p.src_pitch = sp; p.dst_pitch = dp;
+    } else {
+        temp_lock.lock();
+        rc = make_tables(ctx, src, dst, n, s, &tab);
+        if (rc) return rc;
+        p.src_tab = tab.src; p.dst_tab = tab.dst;
+    }
+    p.src_stride = s0.stride; p.dst_stride = d0.stride;
+    p.src_w = s0.width; p.src_h = s0.height; p.dst_w = d0.width; p.dst_h = d0.height;
+    p.src_bytes = (unsigned)src_span; p.dst_bytes = (unsigned)dst_span;
+    p.x_left = xt->left; p.x_weight = xt->weight; p.strip_left = rs->strip_left;
+    p.x_taps = ktaps; p.x_per_lane = per_lane; p.x_step = step; p.x_groups = xt->groups; p.xw_stride = xt->stride;
+    p.n_strips = rs->n_strips; p.stage_pieces = rs->pieces;
+    p.fma = fma;
+    p.r = r; p.g = g; p.b = b;
+    p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc;
+    // row chunks: >= ~4 workgroups per CU in the launch, but every chunk re-stages the `ring` source rows above its first
+    // output: keep that halo under ~8 % of the chunk's own source rows
+    const int ring = std::max(ay->host.span, 1);
+    const long long blocks_per_chunk = (long long)n * rs->n_strips;
+    long long chunks = opt_chunks > 0 ? opt_chunks : (1024 + blocks_per_chunk - 1) / blocks_per_chunk;
+    if (opt_chunks <= 0) {
+        const double src_rows_per_out = std::max(1.0, (double)s0.height / d0.height);
+        const long long min_rows = (long long)std::ceil(ring / (0.08 * src_rows_per_out));
+        chunks = std::min(chunks, std::max<long long>(1, d0.height / std::max<long long>(8, min_rows)));
+    }
+    chunks = std::max<long long>(1, std::min<long long>(chunks, d0.height));
+    p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
+    p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    int done = 0;
+    while (done < n) {
+        const int m = std::min(n - done, 65535);
+        RowsParams q = p;
+        q.n_images = m;
+        if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
+        else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
+        HIP_TRY(launch_resize_rows_kernel(variant, q, s, &g_last_kernel));
+        done += m;
+    }
+    *used = true;
+    if (tab.used) return temp_release(ctx->tables, s);
+    return PICHA_OK;
+}
+
 // ---- resize of one equal-geometry group on device ------------------------------------------------
 int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, int filter,
                  float fscale, hipStream_t s) {
     const picha_image &s0 = src[0], &d0 = dst[0];
     const int pixel = s0.pixel;
+    {
+        long path;
+        { std::lock_guard<std::mutex> lk(g_opt_mu); path = g_opt_path; }
+        if (path == 0 || path == 5) {  // "path" = 5: the row-staged kernel or an error
+            bool used = false;
+            int rcr = rows_group(ctx, src, dst, n, filter, fscale, 0.0f, 0.0f, 0.0f, s, &used);
+            if (rcr || used) return rcr;
+            if (path == 5) return fail(PICHA_ERR_ARGUMENT, "row-staged kernel forced but unsupported for this geometry");
+        }
+    }
     std::shared_ptr<DeviceAxis> ax_ref, ay_ref;  // keep the tables alive while launches are enqueued
     int rc = get_axis(ctx, filter, fscale, s0.width, d0.width, &ax_ref);
     if (rc) return rc;
@@ -1060,7 +1265,8 @@ int run_host(Op op, int n, const picha_image *src, const picha_image *dst, int f
 
     // one device arena and one pinned host mirror of it: [src images | dst images], 256-byte aligned.
     // Transfers go through the pinned mirror as two 1-D copies (pageable / 2-D async copies are
-    // staged by the runtime anyway, and were observed to complete after hipStreamSynchronize).
+    // staged by the runtime through its own bounce buffers anyway: one pinned mirror and 1-D copies keep
+    // every byte of the transfer on this lane's stream).
     std::vector<size_t> soff(n), doff(n);
     size_t total = 0;
     for (int i = 0; i < n; ++i) { soff[i] = total; total += align_up(image_span(src[i]), 256); }
@@ -1231,6 +1437,8 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "stream_rot") == 0) { g_opt_stream_rot = value; return PICHA_OK; }
     if (strcmp(key, "dpp") == 0) { g_opt_dpp = value; return PICHA_OK; }
     if (strcmp(key, "sym") == 0) { g_opt_sym = value; return PICHA_OK; }
+    if (strcmp(key, "rows") == 0) { g_opt_rows = value; return PICHA_OK; }
+    if (strcmp(key, "fuse") == 0) { g_opt_fuse = value; return PICHA_OK; }
     if (strcmp(key, "cc_mode") == 0) { g_opt_cc_mode = value; set_color_convert_mode((int)value); return PICHA_OK; }
     if (strcmp(key, "block_waves") == 0) { g_opt_block_waves = value; return PICHA_OK; }
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
@@ -1250,6 +1458,8 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "stream_rot") == 0) return g_opt_stream_rot;
     if (strcmp(key, "dpp") == 0) return g_opt_dpp;
     if (strcmp(key, "sym") == 0) return g_opt_sym;
+    if (strcmp(key, "rows") == 0) return g_opt_rows;
+    if (strcmp(key, "fuse") == 0) return g_opt_fuse;
     if (strcmp(key, "cc_mode") == 0) return g_opt_cc_mode;
     if (strcmp(key, "block_waves") == 0) return g_opt_block_waves;
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
@@ -1348,6 +1558,15 @@ int picha_hip_convert_resize_device(int n, const picha_image *src, const picha_i
         const picha_image &s0 = src[i], &d0 = dst[i];
         if (s0.pixel == d0.pixel) {  // the convert step is the reference's payload copy: nothing to chain
             rc = resize_group(ctx, src + i, dst + i, j - i, filter, filter_scale, s);
+        } else if ([&] {  // colour convert fused into the row-staged resize: the intermediate never exists in HBM
+                       bool used = false;
+                       rc = PICHA_OK;
+                       long fuse;
+                       { std::lock_guard<std::mutex> lk(g_opt_mu); fuse = g_opt_fuse; }
+                       if (order == PICHA_CONVERT_THEN_RESIZE && fuse != 2) rc = rows_group(ctx, src + i, dst + i, j - i, filter, filter_scale, r, g, b, s, &used);
+                       return rc != PICHA_OK || used;
+                   }()) {
+            // done (or failed) in the fused kernel
         } else {  // (equal sizes still resize: a 1:1 resample is not the identity for every filter)
             // the reference's intermediate image: newJsImage(w, h, pixel), stride = row_stride (src/picha.cc:119-133)
             picha_image mid;

@@ -155,6 +155,38 @@ bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty);
 bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty);
 hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 
+// ---- resize: row-staged kernel (kernels_rows.hip): pixels converted once per row into LDS, optional fused colour convert ----
+struct RowsParams {
+    const uint8_t *src;
+    uint8_t *dst;
+    long long src_pitch, dst_pitch;
+    const void *const *src_tab;
+    void *const *dst_tab;
+    int src_stride, dst_stride;
+    int src_w, src_h, dst_w, dst_h;
+    unsigned src_bytes, dst_bytes;
+    int n_images;
+    // x axis: thread t of strip b owns outputs (b*256 + t)*x_per_lane ..; its window starts at source pixel x_left[group]
+    // (aligned for the LDS reads), the second output's x_step pixels later; weights tap-major [x_taps][xw_stride]
+    const int32_t *x_left;
+    const float *x_weight;
+    const int32_t *strip_left;   // [n_strips] first source pixel a strip stages (a multiple of the stage piece)
+    int x_taps, x_per_lane, x_step, x_groups, xw_stride;
+    int n_strips, stage_pieces;  // stage pieces per thread and row: 1, 2, 4 or 8 (x 256 threads x pixels per piece)
+    int fma;
+    float r, g, b;               // luma weights of the fused colour convert
+    // y axis: the accumulator kernel's per-source-row records
+    const int32_t *yrow_rec, *yrow_range;
+    int nacc;
+    int rows_per_chunk, n_chunks;
+};
+// variant: 0 grey, 1 rgba, 2 rgb -> grey, 3 rgba -> grey, 4 greya, 5 r16g16b16a16 (rows_variant(): -1 if none)
+int rows_variant(int src_pixel, int dst_pixel);
+int rows_stage_pixels(int variant);   // source pixels per stage piece
+int rows_window_align(int variant);   // window starts are multiples of this many pixels (8-byte LDS reads)
+bool rows_kernel_supported(int variant, int per_lane, int step, int taps);
+hipError_t launch_resize_rows_kernel(int variant, const RowsParams &p, hipStream_t s, const char **kernel_name);
+
 // ---- Image helpers on device images (lib/image.js:57-73) -------------------------------------------
 struct CompareParams {
     const void *const *a_tab;  // per-image row-0 pointers (device arrays)

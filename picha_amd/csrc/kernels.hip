@@ -46,6 +46,36 @@ hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_
     return hipErrorInvalidValue;
 }
 
+// defined in kernels_rows.hip, one translation unit per variant
+#define PICHA_DECL_ROWS(N)                                                    \
+    bool rows_supported_variant##N(int per_lane, int step, int taps);          \
+    hipError_t launch_rows_variant##N(const RowsParams &p, hipStream_t s, const char **name);
+PICHA_DECL_ROWS(0) PICHA_DECL_ROWS(1) PICHA_DECL_ROWS(2) PICHA_DECL_ROWS(3) PICHA_DECL_ROWS(4) PICHA_DECL_ROWS(5)
+#undef PICHA_DECL_ROWS
+int rows_variant(int sp, int dp) {
+    if (sp == dp) return sp == 2 ? 0 : sp == 1 ? 1 : sp == 3 ? 4 : sp == 7 ? 5 : -1;
+    if (dp == 2) return sp == 0 ? 2 : sp == 1 ? 3 : -1;
+    return -1;
+}
+int rows_stage_pixels(int v) { return v == 0 ? 4 : v == 1 ? 1 : v == 2 ? 4 : v == 3 ? 4 : v == 4 ? 2 : 1; }
+int rows_window_align(int v) { return (v == 0 || v == 2 || v == 3) ? 2 : 1; }
+bool rows_kernel_supported(int v, int per_lane, int step, int taps) {
+    switch (v) {
+#define PICHA_CASE(N) case N: return rows_supported_variant##N(per_lane, step, taps);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5)
+#undef PICHA_CASE
+    }
+    return false;
+}
+hipError_t launch_resize_rows_kernel(int v, const RowsParams &p, hipStream_t s, const char **name) {
+    switch (v) {
+#define PICHA_CASE(N) case N: return launch_rows_variant##N(p, s, name);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5)
+#undef PICHA_CASE
+    }
+    return hipErrorInvalidValue;
+}
+
 bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot) {
     switch (pixel) {
 #define PICHA_CASE(N) case N: return stream_supported_pixel##N(per_lane, sx, tx, sy, ty, rot);

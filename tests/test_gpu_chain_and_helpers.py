@@ -53,6 +53,99 @@ def test_convert_resize_chain_equals_two_reference_calls(case, order):
     assert np.array_equal(payload(got), payload(want)), "max code diff %d" % max_code_diff(got, want)
 
 
+FUSED_CASES = [
+    # src pixel, src size, dst size, filter, filterScale: downscales where the fused (row-staged) kernel serves the chain
+    ("rgb", (960, 270), (128, 64), "lanczos", 1.0),     # cfg3's structure: 7.5x / 4.2x, two outputs per thread
+    ("rgb", (1200, 120), (150, 30), "mitchel", 1.0),    # 8x, 31 taps: one output per thread
+    ("rgba", (770, 200), (110, 50), "cubic", 0.70),     # rgba -> grey, 7x
+    ("rgb", (300, 200), (130, 90), "cubic", 1.0),       # mild non-integer downscale
+    ("rgb", (97, 61), (13, 9), "lanczos", 1.0),         # tiny
+    ("rgba", (2600, 64), (520, 16), "triangle", 1.0),   # several column strips
+]
+
+
+@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: "%s-%dx%d-%s" % (c[0], c[1][0], c[1][1], c[3]))
+def test_fused_convert_resize_kernel_equals_two_reference_calls(case):
+    """colour convert fused into the resize — the grey intermediate is quantised in registers and
+    never exists in HBM — must equal oracle colorConvert followed by oracle resize bit for bit, and equal the two-kernel
+    chain (option fuse = 2)."""
+    sp, (sw, sh), (dw, dh), filt, fscale = case
+    rng = np.random.default_rng(sw * 7 + dw)
+    for weights, wopts in ((None, {}), (picha.color_settings(0.2, 0.7, 0.1), {"redWeight": 0.2, "greenWeight": 0.7, "blueWeight": 0.1})):
+        img = rand_image(rng, sw, sh, sp, pad=int(rng.choice([0, 4])), edge_values=bool(weights is not None))
+        want = _chain_oracle(img, "grey", dw, dh, 0, weights, filt, fscale)
+        opts = dict({"pixel": "grey", "width": dw, "height": dh, "filter": filt, "filterScale": fscale}, **wopts)
+        names = {}
+        for fuse in (0, 2):
+            for chunks in ((0, 1, 3) if fuse == 0 else (0,)):
+                for per_lane in ((0, 1) if fuse == 0 else (0,)):
+                    N.check(N.lib().picha_hip_set_option(b"fuse", fuse))
+                    N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
+                    N.check(N.lib().picha_hip_set_option(b"per_lane", per_lane))
+                    try:
+                        got = picha.convertResizeSync(img, opts)
+                    finally:
+                        for k in (b"fuse", b"row_chunks", b"per_lane"):
+                            N.check(N.lib().picha_hip_set_option(k, 0))
+                    names[fuse] = N.lib().picha_hip_last_kernel().decode()
+                    assert np.array_equal(payload(got), payload(want)), (case, fuse, chunks, per_lane, names[fuse], max_code_diff(got, want))
+        assert names[0].startswith("resize_rows<src ch%d" % N.PIXEL_CHANNELS[sp]), names
+        assert not names[2].startswith("resize_rows<src ch%d" % N.PIXEL_CHANNELS[sp]), names
+        # fused-multiply-add flavour: within one code value of the reference chain
+        N.check(N.lib().picha_hip_set_option(b"numerics", 1))
+        try:
+            got = picha.convertResizeSync(img, opts)
+        finally:
+            N.check(N.lib().picha_hip_set_option(b"numerics", 0))
+        assert max_code_diff(got, want) <= 1
+
+
+ROWS_CASES = [
+    ("grey", (960, 270), (128, 64), "lanczos", 1.0),          # cfg3b's structure
+    ("grey", (1200, 120), (150, 30), "cubic", 1.0),           # 8x, 31 taps: one output per thread
+    ("rgba", (770, 200), (110, 50), "cubic", 1.0),
+    ("rgba", (3000, 45), (400, 10), "lanczos", 1.0),           # several column strips, one output per thread
+    ("greya", (640, 128), (80, 32), "mitchel", 1.0),
+    ("r16g16b16a16", (640, 96), (96, 24), "catmulrom", 1.0),
+    ("grey", (515, 77), (103, 19), "lanczos", 1.5),           # wider filter scale: 5x with 30 taps
+]
+
+
+@pytest.mark.parametrize("case", ROWS_CASES, ids=lambda c: "%s-%dx%d-%s" % (c[0], c[1][0], c[1][1], c[3]))
+def test_row_staged_downscale_kernel_matches_oracle(case):
+    """The row-staged kernel (pixels converted once per row into LDS, windows read from LDS) against the oracle, for one and
+    two outputs per thread, several row chunkings, padded strides and the fma flavour; option rows = 2 gives the kernels it
+    replaces, which must agree byte for byte."""
+    pixel, (sw, sh), (dw, dh), filt, fscale = case
+    rng = np.random.default_rng(sw + 31 * dw)
+    img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 4, 8])))
+    want = oracle_resize(img, dw, dh, filt, fscale)
+    opts = {"width": dw, "height": dh, "filter": filt, "filterScale": fscale}
+    try:
+        for per_lane in (0, 1):
+            for chunks in (0, 1, 4):
+                N.check(N.lib().picha_hip_set_option(b"rows", 1))
+                N.check(N.lib().picha_hip_set_option(b"per_lane", per_lane))
+                N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
+                got = picha.resizeSync(img, opts)
+                name = N.lib().picha_hip_last_kernel().decode()
+                assert name.startswith("resize_rows<"), name
+                assert max_code_diff(got, want) == 0, (case, per_lane, chunks, name)
+        N.check(N.lib().picha_hip_set_option(b"rows", 2))
+        N.check(N.lib().picha_hip_set_option(b"per_lane", 0))
+        N.check(N.lib().picha_hip_set_option(b"row_chunks", 0))
+        got = picha.resizeSync(img, opts)
+        assert not N.lib().picha_hip_last_kernel().decode().startswith("resize_rows<")
+        assert max_code_diff(got, want) == 0
+        N.check(N.lib().picha_hip_set_option(b"rows", 1))
+        N.check(N.lib().picha_hip_set_option(b"numerics", 1))
+        got = picha.resizeSync(img, opts)
+        assert N.lib().picha_hip_last_kernel().decode().startswith("resize_rows<") and max_code_diff(got, want) <= 1
+    finally:
+        for k in (b"rows", b"per_lane", b"row_chunks", b"numerics"):
+            N.check(N.lib().picha_hip_set_option(k, 0))
+
+
 def test_convert_resize_chain_same_format_is_plain_resize_and_errors_match():
     rng = np.random.default_rng(5)
     img = rand_image(rng, 40, 30, "rgb")

@@ -102,18 +102,77 @@ def test_cfg3_full_size_convert_then_lanczos_pipeline():
 
 
 def test_cfg5_full_size_16bit_mitchel():
-    """configs[4] geometry: 7680x4320 r16g16b16a16 -> 1920x1080 mitchel (a few images)."""
+    """configs[4] geometry: 7680x4320 r16g16b16a16 -> 1920x1080 mitchel.  The planner's own choice (path 0) runs at the FULL
+    size — 61 440-byte source rows, 265 MB per image: 32-bit row * stride and descriptor arithmetic that a small image
+    cannot exercise — and must agree with the span and two-pass kernels on every byte and with the oracle on the first
+    and last image."""
     n = 3
     src = DeviceBatch(n, 7680, 4320, "r16g16b16a16").fill_random(5)
-    sums = set()
-    for path in (3, 1):
+    sums = {}
+    for path in (0, 4, 3, 1):   # planner's choice, accumulator kernel forced, LDS-ring span kernel, two-pass
         set_opt("path", path)
         out = resize_batch(src, 1920, 1080, filter="mitchel")
         torch.cuda.synchronize()
-        sums.add(digest(out))
-    assert len(sums) == 1
+        name = N.lib().picha_hip_last_kernel().decode()
+        if path == 0:
+            assert name.startswith("resize_acc<ch4,u16,TX16,NACC4"), name   # DESIGN.md 5.7: the kernel bench.py times for cfg5
+            planner = out
+        sums[path] = digest(out)
+    assert len(set(sums.values())) == 1, sums
+    for i in (0, n - 1):
+        exp = oracle_resize(src.image_host(i), 1920, 1080, "mitchel", 1.0)
+        assert np.array_equal(planner.image_host(i).pixels(), exp.pixels()), i
+
+
+def test_cfg5_per_gpu_batch_of_128_images_kernel_families_agree():
+    """configs[4] at its per-GPU batch: 128 x 8K r16g16b16a16 (34 GB resident) -> 1080p mitchel.  Too much for the oracle,
+    so the size-independent property: the planner's kernel and the span kernel produce the same digest over all 128
+    outputs, and the oracle confirms the last image (whose bytes sit 34 GB into the batch: 64-bit image pitch)."""
+    n = 128
+    src = DeviceBatch(n, 7680, 4320, "r16g16b16a16").fill_random(6)
+    set_opt("path", 0)
+    a = resize_batch(src, 1920, 1080, filter="mitchel")
+    torch.cuda.synchronize()
+    assert N.lib().picha_hip_last_kernel().decode().startswith("resize_acc<ch4,u16,TX16,NACC4")
+    da = digest(a)
+    set_opt("path", 3)
+    b = resize_batch(src, 1920, 1080, filter="mitchel", out=a)   # reuse the destination batch
+    torch.cuda.synchronize()
+    assert N.lib().picha_hip_last_kernel().decode().startswith("resize_span")
+    assert digest(b) == da
     exp = oracle_resize(src.image_host(n - 1), 1920, 1080, "mitchel", 1.0)
-    assert np.array_equal(out.image_host(n - 1).pixels(), exp.pixels())
+    assert np.array_equal(b.image_host(n - 1).pixels(), exp.pixels())
+
+
+# the format pairs the codecs imply (reference index.js:37-72: supportedMap x each codec's `encodes`; README.md:158-159: tiff
+# always decodes to rgba; src/pngcodec.cc:61-86: `deep` png decodes to the 16-bit formats; src/jpegcodec.cc:512-514 and
+# src/webpcodec.cc:399-401: jpeg encodes rgb / grey, webp encodes rgb / rgba)
+CODEC_EDGE_PAIRS = [
+    ("rgba", "rgb"), ("greya", "grey"), ("r16", "grey"), ("r16g16", "grey"), ("r16g16b16", "rgb"), ("r16g16b16a16", "rgb"),   # -> jpeg
+    ("grey", "rgb"), ("greya", "rgba"), ("r16", "rgb"), ("r16g16", "rgb"), ("r16g16b16a16", "rgba"),                          # -> webp
+    ("rgba", "grey"), ("rgb", "grey"), ("r16g16b16", "rgba"),                                                                  # decode -> analysis
+]
+
+
+@pytest.mark.parametrize("pair", CODEC_EDGE_PAIRS, ids=lambda p: "%s-%s" % p)
+def test_codec_edge_color_converts_at_4k(pair):
+    """Full-size colour converts for every pair a codec boundary implies: the whole batch is checked on the device against the
+    4-pixel kernel (cc_mode 1), two images against the oracle."""
+    sp, dp = pair
+    n = 6
+    src = DeviceBatch(n, 3840, 2160, sp).fill_random(31)
+    out = color_convert_batch(src, dp)
+    torch.cuda.synchronize()
+    set_opt("cc_mode", 1)
+    try:
+        ref = color_convert_batch(src, dp)
+        torch.cuda.synchronize()
+    finally:
+        set_opt("cc_mode", 0)
+    assert torch.equal(out.tensor, ref.tensor)
+    for i in (0, n - 1):
+        exp = oracle_convert(src.image_host(i), dp)
+        assert np.array_equal(out.image_host(i).pixels(), exp.pixels())
 
 
 def test_non_uniform_pitch_batches_use_pointer_tables():
