@@ -9,7 +9,7 @@ from picha_amd.device import DeviceBatch, color_convert_batch
 def opt(k, v): N.check(N.lib().picha_hip_set_option(k.encode(), int(v)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 torch.cuda.set_device(0)
-pairs = [('rgb', 'grey'), ('rgba', 'grey'), ('rgba', 'rgb'), ('rgb', 'rgba'), ('grey', 'rgba'), ('rgba', 'greya'), ('rgba', 'r16g16b16a16'),
+pairs = [('grey', 'greya'), ('grey', 'r16'), ('greya', 'r16g16'), ('rgb', 'grey'), ('rgba', 'grey'), ('rgba', 'rgb'), ('rgb', 'rgba'), ('grey', 'rgba'), ('rgba', 'greya'), ('rgba', 'r16g16b16a16'),
          ('r16g16b16a16', 'rgba'), ('rgb', 'r16g16b16'), ('r16g16b16', 'grey'), ('greya', 'rgba'), ('r16', 'grey')]
 print('%-14s %-14s %-5s %8s %8s %6s' % ('src', 'dst', 'mode', 'ms', 'GB/s', 'frac'))
 for sp, dp in pairs:
@@ -20,7 +20,7 @@ for sp, dp in pairs:
         ref = None
         res = {}
         for rnd in range(3):
-            for mode in (1, 0, 2):
+            for mode in (1, 0, 2, 3):
                 opt('cc_mode', mode)
                 color_convert_batch(src, dp, out=dst); torch.cuda.synchronize()
                 if rnd == 0:
@@ -32,7 +32,7 @@ for sp, dp in pairs:
                 e1.record(); torch.cuda.synchronize()
                 res.setdefault(mode, []).append(e0.elapsed_time(e1) / 8)
         b = nn * w * h * (N.PIXEL_BYTES[sp] + N.PIXEL_BYTES[dp])
-        for mode in (1, 0, 2):
+        for mode in (1, 0, 2, 3):
             t = min(res[mode])
             print('%-14s %-14s %-5d %8.3f %8.1f %6.3f   %dx%d' % (sp, dp, mode, t, b / t / 1e6, b / t / 1e6 / 8000, w, h), flush=True)
         del src, dst, ref

@@ -125,7 +125,7 @@ def test_random_color_converts_match_oracle():
             r, g, b = (float(v) for v in rng.uniform(0.05, 2.0, size=3))
             opts.update(redWeight=r, greenWeight=g, blueWeight=b)
             wts = picha_amd.color_settings(r, g, b)
-        set_opt("cc_mode", int(rng.choice([0, 0, 1, 2])))
+        set_opt("cc_mode", int(rng.choice([0, 0, 1, 2, 3])))
         got = picha_amd.colorConvertSync(img, opts)
         exp = oracle_convert(img, dp, weights=wts)
         assert np.array_equal(payload(got), payload(exp)), (w, h, sp, dp, opts)
