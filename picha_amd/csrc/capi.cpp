@@ -82,6 +82,7 @@ long g_opt_dpp = 0;         // 0 auto, 1 prefer / 2 forbid the cross-lane pixel-
 long g_opt_cc_mode = 0;     // colour convert: 0 auto (wide kernel when rows are dword aligned), 1 always the 4-pixel kernel, 2 wide + nt stores
 long g_opt_sym = 0;         // symmetric-table streaming kernel (kernels_sym.hip): 0 auto (when available), 2 never
 long g_opt_block_waves = 0; // its waves per workgroup (0 auto)
+long g_opt_sym_sync = 0;    // 1: a barrier per step keeps the waves of a workgroup in lockstep
 
 // ---- per-device state ---------------------------------------------------------------------------
 struct DeviceAxis {
@@ -809,10 +810,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (rc) return rc;
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
-    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_bw;
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_bw, opt_sym_sync;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
-        opt_sym = g_opt_sym; opt_bw = g_opt_block_waves;
+        opt_sym = g_opt_sym; opt_bw = g_opt_block_waves; opt_sym_sync = g_opt_sym_sync;
         opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
         opt_rot = g_opt_stream_rot;
         opt_dpp = g_opt_dpp;
@@ -835,7 +836,22 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     }
     int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps, pixel);  // includes alignment room where needed
     const DeviceAxis::XTable *xt = nullptr;
-    if (fused_ok && opt_per_lane != 1 && opt_path != 4) {
+    // upscales by >= 2 of the 8-bit sub-dword formats (rgb, grey, greya): four outputs per lane sharing one window, whole-dword
+    // stores (the one-output-per-lane span kernel is bound by its 1-3 byte stores: 0.15-0.26 of the roof, r01 survey)
+    if (fused_ok && (opt_per_lane == 0 || opt_per_lane == 4) && opt_path != 4 && opt_path != 1 && kBytes[pixel] % 4 != 0 && pixel < PICHA_R16 &&
+        d0.width >= 2 * s0.width) {
+        bool dword_rows = true;
+        for (int i = 0; i < n; ++i)
+            if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % 4) dword_rows = false;
+        const int kt = ax->host.taps + 2;
+        if (dword_rows && fused_multi_supported(pixel, 4, 0, kt) && fused_supported(pixel, kt, ay->host.taps, ring, 4)) {
+            const DeviceAxis::XTable *cx = nullptr;
+            rc = get_xtable(ctx, ax, 4, 0, kt, xw_mode, is16, &cx);
+            if (rc) return rc;
+            if (cx->ok) { xt = cx; per_lane = 4; step = 0; ktaps = kt; }
+        }
+    }
+    if (fused_ok && !xt && opt_per_lane != 1 && opt_path != 4) {
         // integer decimation / interpolation step of the tap windows
         const int st = std::max(1, (int)std::lround((double)s0.width / d0.width));
         static const int cand[] = {2, 4};
@@ -900,6 +916,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 memcpy(p.y_canon, cy->canon, sizeof p.y_canon);
                 p.cx0 = cx->c0; p.cx1 = cx->c1; p.x_base = cx->xbase;
                 p.block_waves = bw;
+                p.sync_steps = opt_sym_sync == 1 ? 1 : 0;
             }
             const long long col_waves = (cx->groups + 63) / 64;
             // row chunks: at least ~32 K waves per launch, chunks of >= 16 output rows.  Every chunk re-reads and
@@ -1441,6 +1458,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "fuse") == 0) { g_opt_fuse = value; return PICHA_OK; }
     if (strcmp(key, "cc_mode") == 0) { g_opt_cc_mode = value; set_color_convert_mode((int)value); return PICHA_OK; }
     if (strcmp(key, "block_waves") == 0) { g_opt_block_waves = value; return PICHA_OK; }
+    if (strcmp(key, "sym_sync") == 0) { g_opt_sym_sync = value; return PICHA_OK; }
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
     if (strcmp(key, "acc") == 0) { g_opt_acc = value; return PICHA_OK; }
     if (strcmp(key, "async_devices") == 0) { g_opt_async_devices = value; return PICHA_OK; }
@@ -1462,6 +1480,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "fuse") == 0) return g_opt_fuse;
     if (strcmp(key, "cc_mode") == 0) return g_opt_cc_mode;
     if (strcmp(key, "block_waves") == 0) return g_opt_block_waves;
+    if (strcmp(key, "sym_sync") == 0) return g_opt_sym_sync;
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
     if (strcmp(key, "acc") == 0) return g_opt_acc;
     if (strcmp(key, "async_devices") == 0) return g_opt_async_devices;

@@ -148,6 +148,7 @@ struct StreamParams {
     int32_t x_canon[8], y_canon[8];
     int cx0, cx1, x_base;
     int block_waves;  // waves per workgroup (1..4)
+    int sync_steps;   // 1: one s_barrier per step keeps a workgroup's waves in lockstep (shared edge lines hit in L1)
 };
 bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot);
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);

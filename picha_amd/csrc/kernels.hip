@@ -179,6 +179,7 @@ hipError_t launch_resize_acc(int pixel, const FusedParams &p, hipStream_t s, con
 }
 
 bool fused_multi_supported(int pixel, int per_lane, int step, int x_taps) {
+    if ((pixel == 0 || pixel == 2 || pixel == 3) && per_lane == 4 && step == 0) return x_taps >= 5 && x_taps <= 7;  // upscales, 4 outputs per lane
     if (pixel != 1) return false;
     const int key = per_lane * 10000 + step * 100 + x_taps;
     return key == 20205 || key == 20207 || key == 40205 || key == 20103 || key == 20104;

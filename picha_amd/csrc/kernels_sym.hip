@@ -150,6 +150,9 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
 #pragma unroll
             for (int t = 0; t < YW; ++t) wb[t] = ystep[(size_t)m * YW + t];
             const bool ycanon = (wb[YW - 1] & 2) != 0;  // all NPEND outputs of this step exist and are canonical
+            // optional: keep the waves of a workgroup (adjacent column strips) on the same step, so the partial lines at
+            // their common edge are fetched once and hit in the CU's L1 (waves that left the kernel do not take part)
+            if (p.sync_steps) __builtin_amdgcn_s_barrier();
 #pragma unroll
             for (int ph = 0; ph < SY; ++ph) {
                 const int T = K * SY + ph;                 // row index inside the unrolled group (a constant after unrolling)

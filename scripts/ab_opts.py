@@ -16,7 +16,7 @@ import picha_amd
 from picha_amd import _native as N
 from picha_amd.device import DeviceBatch, ResizePlan
 
-KNOBS = ('numerics', 'per_lane', 'path', 'row_chunks', 'stream_rot', 'dpp', 'xcd_remap', 'acc', 'sym', 'sym_nbuf', 'block_waves')
+KNOBS = ('numerics', 'per_lane', 'path', 'row_chunks', 'stream_rot', 'dpp', 'xcd_remap', 'acc', 'sym', 'block_waves', 'sym_sync', 'rows')
 
 
 def opt(k, v):

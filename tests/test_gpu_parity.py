@@ -569,6 +569,34 @@ def test_resize_subdword_multi_output_streaming_kernel(pixel):
         assert np.array_equal(payload(odd.image_host(i)), payload(exp)), (pixel, i, name)
 
 
+@pytest.mark.parametrize("pixel", ["rgb", "grey", "greya"])
+def test_upscales_of_subdword_formats_use_four_outputs_per_lane(pixel):
+    """Upscales by >= 2 of the 8-bit sub-dword formats: four outputs per lane sharing one window and whole-dword stores
+    (span kernel, P4, step 0) must equal the oracle and the one-output-per-lane kernel, for every filter, ragged widths,
+    several row chunks and the fma flavour (<= 1)."""
+    rng = np.random.default_rng(600 + N.pixel_index(pixel))
+    seen = 0
+    for (sw, sh, dw, dh) in [(96, 40, 192, 80), (61, 23, 122, 46), (50, 30, 125, 75), (40, 20, 131, 63), (33, 9, 99, 27), (200, 12, 803, 25)]:
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 4])))
+        for filt, fscale in (("cubic", 0.70), ("cubic", 1.0), ("triangle", 1.0), ("lanczos", 1.0), ("box", 1.0)):
+            exp = oracle_resize(img, dw, dh, filt, fscale)
+            opts = {"width": dw, "height": dh, "filter": filt, "filterScale": fscale}
+            for per_lane, chunks in ((0, 0), (0, 3), (1, 0)):
+                set_opt("per_lane", per_lane)
+                set_opt("row_chunks", chunks)
+                got = picha_amd.resizeSync(img, opts)
+                name = N.lib().picha_hip_last_kernel().decode()
+                seen += per_lane == 0 and ",P4,S0," in name
+                assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, filt, per_lane, chunks, name)
+            set_opt("per_lane", 0)
+            set_opt("row_chunks", 0)
+            set_opt("numerics", 1)
+            got = picha_amd.resizeSync(img, opts)
+            set_opt("numerics", 0)
+            assert max_code_diff(got, exp) <= 1, (pixel, filt, N.lib().picha_hip_last_kernel())
+    assert seen >= 10, seen   # the four-outputs-per-lane instantiations did serve the plain 2x-and-more cases
+
+
 def test_kernel_selection_for_the_baseline_workloads():
     """The planner must keep serving BASELINE.json's workloads with the kernels DESIGN.md names (a silent fall back
     to the two-pass kernels is a 10x performance regression that parity tests alone do not see)."""
