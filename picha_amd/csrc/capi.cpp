@@ -634,7 +634,7 @@ int get_rows_strips(DeviceCtx *ctx, DeviceAxis *ax, const DeviceAxis::XTable *xt
         }
         lo -= ((lo % piece_px) + piece_px) % piece_px;  // floor to a stage piece
         sl[b] = lo;
-        const int need = (hi - lo + 1 + 256 * piece_px - 1) / (256 * piece_px);  // +1: an odd span reads one float past its end
+        const int need = (hi - lo + 3 + 256 * piece_px - 1) / (256 * piece_px);  // +3: the last 16-byte read of a span may run past its end
         while (pieces < need) pieces *= 2;
     }
     pieces = std::max(pieces, 2);  // instantiated: 2, 4, 8
@@ -731,7 +731,7 @@ int rows_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, i
         rc = get_rows_strips(ctx, ax, cx, sh.step * (sh.per_lane - 1) + sh.taps, piece_px, &cs);
         if (rc) return rc;
         if (!cs->ok) continue;
-        if ((size_t)2 * cs->pieces * 256 * piece_px * chl * 4 + 16 > 96 * 1024) continue;  // LDS: keep >= 1 workgroup per SIMD pair
+        if ((size_t)2 * cs->pieces * 256 * piece_px * chl * 4 + 32 > 96 * 1024) continue;  // LDS: keep >= 1 workgroup per SIMD pair
         xt = cx; rs = cs; per_lane = sh.per_lane; step = sh.step; ktaps = sh.taps;
         break;
     }

@@ -183,9 +183,10 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(RowsParams p) {
             }
         };
         if constexpr (CHL == 1) {
-            // 8-byte reads.  (The compiler pairs them into ds_read2_b64, half the LDS rate of ds_read_b64; issuing plain
-            // ds_read_b64 by hand with counted waits was measured 10 % SLOWER on cfg3b — the hand-placed waits expose the
-            // LDS latency the compiler's interleaving hides — so the reads are left to it: profiles/r02_ab_rows_*.txt.)
+            // 8-byte reads, windows aligned to 8 bytes.  Two alternatives were measured on cfg3b and lost (profiles/r02_ab_rows_*.txt):
+            // plain ds_read_b64 issued by hand with counted waits instead of the compiler's ds_read2_b64 pairs (10 % slower: the
+            // hand-placed waits expose the LDS latency the compiler's interleaving hides), and 16-byte aligned windows read as
+            // float4 (4 more padded taps per output: -6 % against the accumulator kernel instead of -11 %)
 #pragma unroll
             for (int i = 0; i < SPANPX; i += 2) {  // an odd span reads one float past its end: inside the buffer's slack
                 const float2 u = *reinterpret_cast<const float2 *>(wp + i);
@@ -262,7 +263,7 @@ template <int SCH, bool SS16, int CH, bool S16, int P, int S, int TXB, int KST, 
 hipError_t launch_rows_t(const RowsParams &p, hipStream_t s, const char **name) {
     constexpr int CHL = rows_lds_floats(CH);
     constexpr int PXT = rows_stage_px(SCH * (SS16 ? 2 : 1), CHL);
-    const size_t lds = (size_t)2 * KST * 256 * PXT * CHL * sizeof(float) + 16;  // + slack for the last odd-span read
+    const size_t lds = (size_t)2 * KST * 256 * PXT * CHL * sizeof(float) + 32;  // + slack for the last read of a span that is not a whole number of 8 / 16-byte pieces
     auto kf = p.fma ? resize_rows_kernel<SCH, SS16, CH, S16, P, S, TXB, KST, NACC, true> : resize_rows_kernel<SCH, SS16, CH, S16, P, S, TXB, KST, NACC, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
