@@ -82,6 +82,7 @@ long g_opt_dpp = 0;         // 0 auto, 1 prefer / 2 forbid the cross-lane pixel-
 long g_opt_cc_mode = 0;     // colour convert: 0 auto (wide kernel when rows are dword aligned), 1 always the 4-pixel kernel, 2 wide + nt stores
 long g_opt_sym = 0;         // symmetric-table streaming kernel (kernels_sym.hip): 0 auto (when available), 2 never
 long g_opt_block_waves = 0; // its waves per workgroup (0 auto)
+long g_opt_acc_p2 = 0;      // accumulator kernel with two outputs per lane: 0 auto (measured table), 1 whenever possible, 2 never
 long g_opt_sym_sync = 0;    // 1: a barrier per step keeps the waves of a workgroup in lockstep
 
 // ---- per-device state ---------------------------------------------------------------------------
@@ -593,13 +594,26 @@ int make_tables(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, 
     return PICHA_OK;
 }
 
+// Where the accumulator kernel with two outputs per lane was measured faster than with one (filled from the r02 survey,
+// profiles/r02_survey_acc_p2.txt): (format, integer step, padded taps, flavour)
+bool acc_p2_preferred(int pixel, int step, int taps, int fma) {
+    if (fma) return false;  // only the reference-arithmetic flavour was surveyed
+    switch (pixel) {
+    case PICHA_RGBA: return (step == 4 && (taps == 12 || taps == 16)) || (step == 3 && taps == 12);   // -7.9 %, -6.8 %, -3.3 %
+    case PICHA_RGB: return step == 4 && taps == 12;                                                   // -3.5 %
+    case PICHA_GREY: return step == 4 && taps == 16;                                                  // -8.4 %
+    case PICHA_R16: return step == 2 && taps == 8;                                                    // -7.5 %
+    }
+    return false;
+}
+
 // Outputs per lane for which resize_sym_kernel beats the general streaming / accumulator kernels by >= 2 % (0: it does not):
 // interleaved survey of all 8 formats x {2x: 3, 5, 7 taps; 3x: 8, 12; 4x: 11, 15} on 64 x 4K images, both numerics flavours
 // (scripts/survey_sym.py, profiles/r02_survey_sym_exact.txt, r02_survey_sym_fma.txt).
 int sym_preferred_per_lane(int pixel, int step, int taps, int fma) {
     struct E { int8_t step, taps, exact, fma; };
     static const E rgb[] = {{2, 5, 0, 4}, {3, 8, 4, 0}, {4, 11, 0, 4}, {4, 15, 0, 4}, {0, 0, 0, 0}};
-    static const E rgba[] = {{2, 5, 3, 2}, {2, 7, 0, 2}, {3, 8, 2, 2}, {4, 11, 2, 2}, {4, 15, 0, 2}, {0, 0, 0, 0}};
+    static const E rgba[] = {{2, 5, 3, 2}, {2, 7, 0, 2}, {3, 8, 2, 2}, {4, 11, 0, 2} /* exact: the two-output accumulator kernel is ahead */, {4, 15, 0, 2}, {0, 0, 0, 0}};
     static const E grey[] = {{2, 5, 0, 4}, {2, 7, 0, 4}, {0, 0, 0, 0}};
     static const E greya[] = {{2, 3, 0, 2}, {2, 5, 0, 4}, {2, 7, 0, 4}, {3, 8, 2, 2}, {3, 12, 2, 0}, {0, 0, 0, 0}};
     static const E r16[] = {{2, 3, 4, 2}, {2, 5, 4, 4}, {2, 7, 4, 4}, {3, 8, 2, 2}, {3, 12, 2, 2}, {4, 11, 2, 2}, {0, 0, 0, 0}};
@@ -810,10 +824,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (rc) return rc;
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
-    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_bw, opt_sym_sync;
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_bw, opt_sym_sync, opt_acc_p2;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
-        opt_sym = g_opt_sym; opt_bw = g_opt_block_waves; opt_sym_sync = g_opt_sym_sync;
+        opt_sym = g_opt_sym; opt_bw = g_opt_block_waves; opt_sym_sync = g_opt_sym_sync; opt_acc_p2 = g_opt_acc_p2;
         opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
         opt_rot = g_opt_stream_rot;
         opt_dpp = g_opt_dpp;
@@ -1017,7 +1031,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     // 7 waves per CU); the accumulator kernel keeps nacc x channels registers instead.
     const DeviceAxis::YRows *yr = nullptr;
     const DeviceAxis::XTable *xa = nullptr;
-    int nacc = 0;
+    int nacc = 0, acc_per_lane = 1, acc_x_step = 1;
     constexpr int kAccMinRing = 1;  // measured faster than the span kernel for every ring size it was tried on (profiles/r01_survey_acc_vs_span.txt)
     int ataps = fused_x_bucket(ax->host.taps, pixel, true);  // the accumulator kernel's own (finer) x bucket
     const bool acc_long = ataps == 0 && ax->host.taps > 36 && ax->host.taps <= 128;
@@ -1034,11 +1048,27 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             if (rc) return rc;
             if (cand->ok) { yr = cand; nacc = na; break; }
         }
-        if (yr) {
+        // two outputs per lane (r02): the union of both windows is loaded and converted once; option "acc_p2": 0 auto (where
+        // acc_p2_preferred says it was measured faster), 1 whenever a shape exists, 2 never
+        int acc_pl = 1, acc_step = 1;
+        if (yr && !acc_long && opt_acc_p2 != 2 && (opt_per_lane == 0 || opt_per_lane == 2)) {
+            const int st = (int)std::floor((double)s0.width / d0.width);
+            static const int shapes[][2] = {{2, 8}, {3, 12}, {4, 12}, {4, 16}};
+            for (auto &e : shapes) {
+                if (e[0] != st || !acc_p2_supported(pixel, e[0], e[1], nacc)) continue;
+                if (opt_acc_p2 == 0 && !acc_p2_preferred(pixel, e[0], e[1], fma)) continue;
+                const DeviceAxis::XTable *cx = nullptr;
+                rc = get_xtable(ctx, ax, 2, e[0], e[1], xw_mode, is16, &cx);
+                if (rc) return rc;
+                if (cx->ok) { xa = cx; acc_pl = 2; acc_step = e[0]; ataps = e[1]; break; }
+            }
+        }
+        if (yr && acc_pl == 1) {
             rc = get_xtable(ctx, ax, 1, 1, ataps, xw_mode, is16, &xa, (!acc_long && fused_x_bytespan(ataps, pixel)) ? kBytes[pixel] : 0);
             if (rc) return rc;
             if (!xa->ok) yr = nullptr;
         }
+        acc_per_lane = acc_pl; acc_x_step = acc_step;
     }
     if (opt_path == 4 && !yr) return fail(PICHA_ERR_ARGUMENT, "accumulator kernel forced but unsupported for this geometry");
     const bool use_acc = yr != nullptr;
@@ -1082,7 +1112,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         p.y_taps = ay->host.taps; p.y_pad = ay->y_pad;
         p.ring_slots = ring;
         p.xcd_remap = opt_xcd == 1 ? 1 : 0;
-        if (use_acc) { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; p.x_per_lane = 1; p.x_step = 1; }
+        if (use_acc) { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; p.x_per_lane = acc_per_lane; p.x_step = acc_x_step; }
         // row chunks: enough waves to fill 256 CUs several times over (~32 K), but every chunk re-resamples the `ring`
         // source rows above its first output: keep that halo under ~6 % of the chunk's own source rows unless the
         // launch would then have fewer than ~8 K waves (4K -> 512x288 thumbnails: 18 -> 6 chunks, -5 %)
@@ -1459,6 +1489,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "cc_mode") == 0) { g_opt_cc_mode = value; set_color_convert_mode((int)value); return PICHA_OK; }
     if (strcmp(key, "block_waves") == 0) { g_opt_block_waves = value; return PICHA_OK; }
     if (strcmp(key, "sym_sync") == 0) { g_opt_sym_sync = value; return PICHA_OK; }
+    if (strcmp(key, "acc_p2") == 0) { g_opt_acc_p2 = value; return PICHA_OK; }
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
     if (strcmp(key, "acc") == 0) { g_opt_acc = value; return PICHA_OK; }
     if (strcmp(key, "async_devices") == 0) { g_opt_async_devices = value; return PICHA_OK; }
@@ -1481,6 +1512,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "cc_mode") == 0) return g_opt_cc_mode;
     if (strcmp(key, "block_waves") == 0) return g_opt_block_waves;
     if (strcmp(key, "sym_sync") == 0) return g_opt_sym_sync;
+    if (strcmp(key, "acc_p2") == 0) return g_opt_acc_p2;
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
     if (strcmp(key, "acc") == 0) return g_opt_acc;
     if (strcmp(key, "async_devices") == 0) return g_opt_async_devices;

@@ -88,6 +88,7 @@ struct FusedParams {
 // so its tap count is a multiple of half a segment.
 constexpr int acc_long_segment(int bytes_per_pixel) { return bytes_per_pixel <= 3 ? 32 : (bytes_per_pixel <= 6 ? 16 : 8); }
 bool acc_supported(int pixel, int x_taps_bucket, int nacc);
+bool acc_p2_supported(int pixel, int step, int taps, int nacc);  // two outputs per lane: window of the second `step` pixels after the first
 hipError_t launch_resize_acc(int pixel, const FusedParams &p, hipStream_t s, const char **kernel_name);
 // True if a fused instantiation exists for this format / tap counts and its LDS ring fits.
 bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots, int per_lane);

@@ -157,6 +157,9 @@ bool fused_x_bytespan(int x_taps_bucket, int pixel) {  // aligned fetch: the hos
     return bpp % 4 != 0 && !span_rotate(bpp, x_taps_bucket);
 }
 
+bool acc_p2_supported(int pixel, int step, int taps, int nacc) {
+    return pixel >= 0 && pixel <= 7 && (nacc == 4 || nacc == 6) && acc_p2_shape(step, taps);
+}
 bool acc_supported(int pixel, int x_taps_bucket, int nacc) {
     if (pixel < 0 || pixel > 7 || (nacc != 4 && nacc != 6)) return false;
     if (x_taps_bucket > 36) {  // resize_acc_long_kernel: multiples of half a segment

@@ -115,7 +115,7 @@ def test_reference_arithmetic_kernels_have_no_fused_multiply_add(device_disassem
     for name, body in kernels.items():
         # template tails: resize_span_kernel<..., bool FMA>, resize_stream_kernel<..., bool FMA, bool ROT>
         m = re.search(r"resize_span_kernelI.*ELb([01])EEEvNS_", name) or \
-            re.search(r"resize_acc(?:_long)?_kernelI.*ELb([01])EEEvNS_", name) or \
+            re.search(r"resize_acc(?:_long)?_kernelI.*ELb([01])(?:ELi\d+ELi\d+)?EEEvNS_", name) or \
             re.search(r"resize_stream_kernelI.*ELb([01])ELb[01]EEEvNS_", name) or \
             re.search(r"resize_stream_dpp_kernelI.*ELb([01])EEEvNS_", name) or \
             re.search(r"resize_sym_kernelI.*ELb([01])EEEvNS_", name) or \

@@ -17,7 +17,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows"):
         set_opt(k, 0)
 
 
@@ -95,6 +95,8 @@ def test_random_resizes_match_oracle(seed):
         set_opt("stream_rot", int(rng.choice([0, 1, 2])))
         set_opt("xcd_remap", int(rng.choice([0, 1, 2])))
         set_opt("acc", int(rng.choice([0, 0, 1, 2])))
+        set_opt("acc_p2", int(rng.choice([0, 0, 1, 2])))
+        set_opt("rows", int(rng.choice([0, 0, 1, 2])))
         try:
             got = picha_amd.resizeSync(img, opts)
         except picha_amd.PichaError as e:

@@ -38,6 +38,7 @@ def _reset_path():
     set_opt("cc_mode", 0)
     set_opt("fuse", 0)
     set_opt("rows", 0)
+    set_opt("acc_p2", 0)
 
 
 def test_device_is_gfx950():
@@ -595,6 +596,38 @@ def test_upscales_of_subdword_formats_use_four_outputs_per_lane(pixel):
             set_opt("numerics", 0)
             assert max_code_diff(got, exp) <= 1, (pixel, filt, N.lib().picha_hip_last_kernel())
     assert seen >= 10, seen   # the four-outputs-per-lane instantiations did serve the plain 2x-and-more cases
+
+
+@pytest.mark.parametrize("pixel", PIXELS)
+def test_accumulator_kernel_two_outputs_per_lane(pixel):
+    """resize_acc_kernel with two outputs per lane (the union of both windows loaded and converted once): every instantiated
+    shape (steps 2, 3, 4) forced with acc_p2 = 1 against the oracle, ragged widths, left-edge lanes whose span starts before
+    the image, several row chunks, padded strides; fma flavour <= 1."""
+    rng = np.random.default_rng(900 + N.pixel_index(pixel))
+    served = 0
+    for (sw, sh, dw, dh, opts) in [(400, 90, 160, 36, {}),                       # 2.5x default: step 2, 8 taps
+                                   (390, 61, 130, 20, {"filter": "mitchel"}),    # 3x mitchel: step 3, 12 taps
+                                   (520, 64, 130, 16, {}),                       # 4x default: step 4, 12 taps
+                                   (517, 70, 129, 17, {"filter": "cubic"}),      # ~4x cubic: step 4, 16 taps
+                                   (1300, 40, 325, 10, {"filter": "mitchel"})]:  # 4x mitchel, several workgroups
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8 if N.PIXEL_BYTES[pixel] == 8 else 4])))  # rows stay naturally aligned
+        filt = opts.get("filter", "cubic")
+        exp = oracle_resize(img, dw, dh, filt, 1.0 if opts else 0.70)
+        for chunks in (0, 3):
+            set_path(4)
+            set_opt("acc_p2", 1)
+            set_opt("row_chunks", chunks)
+            got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
+            name = N.lib().picha_hip_last_kernel().decode()
+            served += ",P2,S" in name
+            assert name.startswith("resize_acc<"), name
+            assert max_code_diff(got, exp) == 0, (pixel, sw, dw, opts, chunks, name)
+        set_opt("numerics", 1)
+        got = picha_amd.resizeSync(img, dict(opts, width=dw, height=dh))
+        set_opt("numerics", 0)
+        assert max_code_diff(got, exp) <= 1
+        set_path(0); set_opt("acc_p2", 0); set_opt("row_chunks", 0)
+    assert served >= 6, served
 
 
 def test_kernel_selection_for_the_baseline_workloads():
