@@ -60,20 +60,36 @@ def _cpu_model():
     return "unknown"
 
 
-def cpu_baseline(name, budget_images=96):
-    """The oracle (CPU port of reference src/resize.cc:66-134) on a bounded sample of the workload, at 1 thread, at 4 threads
-    (libuv's default pool size = the reference's real async concurrency) and on all host cores."""
+# The reference's own code (src/resize.cc:66-134 compiled unmodified, g++ -O3, 1 thread) as timed by the survey on the build
+# container ("Reference CPU path, measured during the survey"): printed beside the port's figure, SURVEY.md 8(d).
+REFERENCE_SURVEY = {
+    "cfg2_4k_rgba_to_1080p_cubic": {"mpix_s": 90.8, "ms_per_image": 91.3},
+    "cfg2_4k_rgba_to_1080p_cubic_scale1": {"mpix_s": 71.7, "ms_per_image": 115.7},
+    "cfg3b_4k_grey_to_512_lanczos": {"mpix_s": 198.0, "ms_per_image": 41.8},
+    "cfg5_8k_rgba16_to_1080p_mitchel": {"mpix_s": 75.4, "ms_per_image": 440.0},
+    "cfg1_640x480_rgba_to_320x240": {"mpix_s": 114.0, "ms_per_image": 2.69},
+}
+REFERENCE_SURVEY_HW = "1 thread, 1 of 8 vCPU Intel Xeon 2.1 GHz (KVM guest, the survey container); BASELINE.md"
+
+
+def _host_threads():
+    try:
+        return max(1, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        return max(1, os.cpu_count() or 1)
+
+
+def cpu_baseline(name, budget_images=256):
+    """The oracle (CPU port of reference src/resize.cc:66-134, specialised per pixel format like the reference's templates) on
+    a bounded sample of the workload, at 1 thread, at 4 threads (libuv's default pool size = the reference's real async
+    concurrency) and on every host core this process may run on."""
     import numpy as np
 
     import oracle
     n, sw, sh, pixel, dw, dh, opts = WORKLOADS[name]
     filt = opts.get("filter", "cubic")
     fscale = opts.get("filterScale", 1.0 if "filter" in opts else 0.70)
-    threads = min(os.cpu_count() or 1, 32)
-    try:
-        threads = min(threads, len(os.sched_getaffinity(0)))
-    except AttributeError:
-        pass
+    threads = _host_threads()
     bpp = {"rgba": 4, "grey": 1, "r16g16b16a16": 8, "rgb": 3, "greya": 2, "r16": 2, "r16g16": 4, "r16g16b16": 6}[pixel]
     big = sw * sh * bpp > 100e6
     rng = np.random.default_rng(20250226)
@@ -89,11 +105,12 @@ def cpu_baseline(name, budget_images=96):
         return {"value": round(n_img * sw * sh / dt / 1e6, 2), "cores": nthreads,
                 "sample": "%d images (%d distinct), one image per thread on %d thread(s), %.2f s wall" % (n_img, distinct, nthreads, dt)}
 
-    n_all = threads if big else max(threads, min(budget_images, threads * 4))
+    # about 10-30 s of CPU work in total: 2-4 images per thread on all cores
+    n_all = threads * 2 if big else max(threads, min(budget_images, threads * 4))
     one = run(1, 2 if big else 8)
     four = run(min(4, threads), 4 if big else 16)
     full = run(threads, n_all)
-    return {
+    out = {
         "value": full["value"],
         "unit": "Mpix/s",
         "cores": threads,
@@ -103,6 +120,12 @@ def cpu_baseline(name, budget_images=96):
         "threads_1": one,
         "threads_4_libuv_default": four,
     }
+    ref = REFERENCE_SURVEY.get(name)
+    if ref:
+        out["reference_survey_mpix_s"] = ref["mpix_s"]
+        out["reference_survey_ms_per_image"] = ref["ms_per_image"]
+        out["reference_survey_hw"] = REFERENCE_SURVEY_HW
+    return out
 
 
 def main():
@@ -137,9 +160,14 @@ def main():
                   % (args.gpus, world, args.gpus), file=sys.stderr)
         args.gpus = world
     ndev = max(1, torch.cuda.device_count())
-    dev = torch.device("cuda", local_rank % ndev)  # one rank per GPU; the modulo only matters for rehearsals on a smaller box
-    torch.cuda.set_device(dev)
     backend = os.environ.get("PICHA_BENCH_BACKEND", "nccl")  # "nccl" == RCCL on ROCm; "gloo" to rehearse N ranks on one GPU
+    if backend == "nccl" and world > 1 and local_rank >= ndev:
+        # a real (RCCL) run is one rank per GPU: more local ranks than visible devices would silently double up
+        print("bench.py: LOCAL_RANK %d but only %d visible GPU(s); one rank per GPU is required with the nccl backend"
+              % (local_rank, ndev), file=sys.stderr)
+        sys.exit(2)
+    dev = torch.device("cuda", local_rank % ndev)  # the modulo only matters for gloo rehearsals on a smaller box
+    torch.cuda.set_device(dev)
     if world > 1:
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -205,9 +233,8 @@ def main():
     for _ in range(args.warmup):
         plan.run()
     torch.cuda.synchronize()
-    kernel = "color_convert_kernel<%s->%s>" % (pixel, convert_to) if convert_to else N.lib().picha_hip_last_kernel().decode()
-    if chained:
-        kernel += " + " + N.lib().picha_hip_last_kernel().decode()
+    # what was launched (picha_hip_last_kernel): a fused convert+resize is ONE kernel; a chained pair reports the last one
+    kernel = N.lib().picha_hip_last_kernel().decode()
 
     # per-launch durations from events on the launch stream (torch's current stream); the barrier-bracketed timing and
     # the max over ranks are picha_amd.shard.timed_region — the same code the two-rank gloo test exercises

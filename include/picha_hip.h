@@ -116,32 +116,56 @@ int picha_hip_device_count(void); /* number of visible HIP devices (0 if none / 
 /* Name of the gcnArch of the current device into buf (e.g. "gfx950"). */
 int picha_hip_device_arch(char *buf, size_t len);
 /*
- * Tuning / test knobs (outside the drop-in surface).  Keys:
+ * Tuning / test knobs (outside the drop-in surface; process-global, read once per call under a lock).  Every key
+ * picha_hip_set_option accepts:
  *   "numerics"   0 = reference arithmetic, bit-identical results (default); 1 = fused multiply-add
  *                flavour of the resize kernels, at most one code value from the reference
  *                (environment: PICHA_HIP_NUMERICS=fma sets the initial value)
  *   "path"       0 = auto, 1 = force the two-pass scratch kernels, 2 = force a fused kernel (error if
  *                none applies), 3 = the LDS-ring span kernel (never the streaming or accumulator kernels),
- *                4 = the accumulator kernel (error if the tap table is not representable)
- *   "acc"        accumulator kernel: 0 = auto (when the span kernel's ring would be large), 1 = whenever
- *                representable, 2 = never
- *   "per_lane"   0 = auto, else output columns per lane for the fused kernels (1, 2, 4)
+ *                4 = the accumulator kernel (error if the tap table is not representable), 5 = the row-staged
+ *                LDS kernel (error if it does not apply).  Chained convert + resize calls honour it too: the
+ *                fused convert+resize kernel is only taken for 0 and 5
+ *   "acc"        accumulator kernel: 0 = auto, 1 = whenever representable, 2 = never
+ *   "acc_p2"     accumulator kernel with two outputs per lane: 0 = auto (measured table), 1 = whenever a shape
+ *                exists, 2 = never
+ *   "per_lane"   0 = auto, else output columns per lane for the fused kernels (1, 2, 3, 4; 3 only in the
+ *                symmetric-table kernel)
  *   "row_chunks" 0 = auto, else number of row chunks per image for the fused kernels
  *   "stream_rot" 0 = auto, 1 / 2 = force the rotating-accumulator / unrolled variant of the streaming kernel
- *   "dpp"        1 = use the cross-lane pixel-sharing streaming kernel where it applies (rgba, 2x, 5 taps)
- *   "xcd_remap"  streaming kernel: 0 = auto, 1 = always / 2 = never permute workgroup ids so that each XCD works
+ *   "dpp"        1 = use the cross-lane pixel-sharing streaming kernel where it applies (rgba, 2x, 5 taps), 2 = never
+ *   "sym"        symmetric-table streaming kernel (integer scales): 0 = auto, 2 = never
+ *   "xch"        neighbour-exchange form of the symmetric-table / accumulator kernels (a lane loads only the pixels
+ *                it owns and takes the rest of its window from the two neighbouring lanes): 0 = auto (measured
+ *                table), 1 = wherever an instantiation exists, 2 = never
+ *   "block_waves"  waves per workgroup of the symmetric-table kernel (1..4, 0 = auto)
+ *   "sym_sync"   1 = one barrier per step keeps the waves of such a workgroup on the same source rows
+ *   "rows"       row-staged LDS downscale kernel: 0 = auto, 1 = whenever it applies, 2 = never
+ *   "fuse"       picha_hip_convert_resize*: 0 = one fused kernel where it exists (default), 2 = always two kernels
+ *   "cc_mode"    colour convert layout: 0 = auto, 1 = the 4-pixel kernel, 2 = wide kernel with non-temporal
+ *                stores, 3 = store-shaped kernel for expanding pairs
+ *   "xcd_remap"  streaming kernels: 0 = auto, 1 = always / 2 = never permute workgroup ids so that each XCD works
  *                through a contiguous range of (column strip, row chunk, image) and neighbours share its L2
  *   "async_devices"  asynchronous entry points: 0 = queue on the caller's current device (default); N > 0 = deal
  *                requests round-robin to the first min(N, visible) devices, one dispatcher each — a single host
  *                process then drives every GPU of a node with independent images (environment:
  *                PICHA_HIP_ASYNC_DEVICES)
+ *   "async_virtual_devices"  1 = "async_devices" may exceed the visible device count (dispatcher k runs on device
+ *                k mod visible; at most 8 dispatchers per device) — rehearses the spread on a one-GPU box
  *   "chain_window_mb"  size of the intermediate buffer of picha_hip_convert_resize* in MB (default 4096)
  * Returns PICHA_ERR_ARGUMENT for an unknown key.
  */
 int picha_hip_set_option(const char *key, long value);
 long picha_hip_get_option(const char *key);
-/* Name of the kernel instantiation the last resize on this thread launched
- * ("resize_stream<...>", "resize_span<...>" or "twopass"). */
+/* Name of the kernel instantiation the last device operation on this thread launched (diagnostics, bench JSON):
+ *   "resize_sym<...>"        symmetric-table streaming kernel (",xch": neighbour-exchange form)
+ *   "resize_stream<...>"     general streaming kernel (",rot": rotating accumulators), "resize_stream_dpp<...>"
+ *   "resize_acc<...>"        accumulator kernel ("P2": two outputs per lane, ",xch"), "resize_acc_long<...>" (> 36 taps)
+ *   "resize_rows<...>"       row-staged LDS kernel ("src chN -> chM": colour convert fused in)
+ *   "resize_span<...>"       LDS-ring span kernel (upscales, ring-aliasing cases)
+ *   "twopass"                hpass_generic + vpass_generic through an HBM scratch
+ *   "color_convert_wide<a->b,..>", "color_convert_expand<a->b>", "color_convert<a->b,4px>"
+ *   "A + B"                  a chained convert + resize that ran as two kernels */
 const char *picha_hip_last_kernel(void);
 
 /* ---- the hot path: host-pointer entry points -------------------------------------------------

@@ -34,7 +34,7 @@ static inline float std_minf(float a, float b) { return (b < a) ? b : a; }
 static inline float std_maxf(float a, float b) { return (a < b) ? b : a; }
 
 /* i::linear_unpack<N,T>  picha.h:98-105:  (*s - i) * (1 / (a - i))  with i = 0.0f, a = float(max) */
-static inline void unpack_px(int pixel, const void *src, float *dst) {
+static inline __attribute__((always_inline)) void unpack_px(const int pixel, const void *src, float *dst) {
     int n = k_channels[pixel];
     if (is16(pixel)) {
         const uint16_t *s = (const uint16_t *)src;
@@ -48,7 +48,7 @@ static inline void unpack_px(int pixel, const void *src, float *dst) {
 }
 
 /* i::linear_pack<N,T>  picha.h:107-114:  T(max(i, min(a, i + v * (a - i) + 0.5f))) */
-static inline void pack_px(int pixel, const float *src, void *dst) {
+static inline __attribute__((always_inline)) void pack_px(const int pixel, const float *src, void *dst) {
     int n = k_channels[pixel];
     if (is16(pixel)) {
         uint16_t *d = (uint16_t *)dst;
@@ -205,12 +205,14 @@ int oracle_make_contribs(int filter, float filter_scale, int src_size, int dst_s
 
 /* ---- resizeImagePixel: src/resize.cc:66-134 ------------------------------------------------ */
 
-int oracle_resize(const oracle_image *src, const oracle_image *dst, int filter_tag, float filter_scale) {
-    if (src->pixel != dst->pixel) return -5; /* assert resize.cc:137 */
-    if (src->pixel < 0 || src->pixel > 7) return -1;
+/* The reference instantiates resizeImagePixel<Pixel, Filter> per pixel format (resize.cc:136-149), so its unpack / pack
+ * loops have compile-time channel counts and sample types.  This body is force-inlined into one wrapper per format
+ * below with `pixel` a literal: same statements, same order, same rounding points — only the dispatch moves out of
+ * the per-tap loop (a run-time `pixel` there made this port 2.6x slower than the code it restates). */
+static inline __attribute__((always_inline)) int resize_pixel_body(const oracle_image *src, const oracle_image *dst,
+                                                                   int filter_tag, float filter_scale, const int pixel) {
     scaled_filter filter;
     if (make_filter(filter_tag, filter_scale, &filter)) return -3;
-    const int pixel = src->pixel;
     const int pixelChannels = k_channels[pixel];
     const int pixelBytes = k_bytes[pixel];
 
@@ -278,6 +280,31 @@ done:
     return rc;
 }
 
+#define ORACLE_RESIZE_PIXEL(P)                                                                                   \
+    static __attribute__((noinline)) int resize_pixel_##P(const oracle_image *src, const oracle_image *dst, int filter_tag, \
+                                                          float filter_scale) {                                  \
+        return resize_pixel_body(src, dst, filter_tag, filter_scale, P);                                         \
+    }
+ORACLE_RESIZE_PIXEL(0) ORACLE_RESIZE_PIXEL(1) ORACLE_RESIZE_PIXEL(2) ORACLE_RESIZE_PIXEL(3)
+ORACLE_RESIZE_PIXEL(4) ORACLE_RESIZE_PIXEL(5) ORACLE_RESIZE_PIXEL(6) ORACLE_RESIZE_PIXEL(7)
+#undef ORACLE_RESIZE_PIXEL
+
+/* resizeImage<Filter> 8-way pixel switch  resize.cc:136-149 */
+int oracle_resize(const oracle_image *src, const oracle_image *dst, int filter_tag, float filter_scale) {
+    if (src->pixel != dst->pixel) return -5; /* assert resize.cc:137 */
+    switch (src->pixel) {
+    case 0: return resize_pixel_0(src, dst, filter_tag, filter_scale);
+    case 1: return resize_pixel_1(src, dst, filter_tag, filter_scale);
+    case 2: return resize_pixel_2(src, dst, filter_tag, filter_scale);
+    case 3: return resize_pixel_3(src, dst, filter_tag, filter_scale);
+    case 4: return resize_pixel_4(src, dst, filter_tag, filter_scale);
+    case 5: return resize_pixel_5(src, dst, filter_tag, filter_scale);
+    case 6: return resize_pixel_6(src, dst, filter_tag, filter_scale);
+    case 7: return resize_pixel_7(src, dst, filter_tag, filter_scale);
+    }
+    return -1;
+}
+
 /* ---- colour convert: src/colorconvert.cc:6-188 ------------------------------------------------ */
 
 void oracle_color_settings(double r, double g, double b, float out[3]) {
@@ -292,7 +319,7 @@ void oracle_color_settings(double r, double g, double b, float out[3]) {
 }
 
 /* ChannelConvertOp<S,D> colorconvert.cc:24-134 — selected by channel COUNT only */
-static inline void channel_convert(int sc, int dc, float r, float g, float b, const float *s, float *d) {
+static inline __attribute__((always_inline)) void channel_convert(const int sc, const int dc, float r, float g, float b, const float *s, float *d) {
     if (sc == dc) { for (int i = 0; i < sc; ++i) d[i] = s[i]; return; }
     switch (sc * 10 + dc) {
     case 12: d[0] = s[0]; d[1] = 1; break;
@@ -310,6 +337,40 @@ static inline void channel_convert(int sc, int dc, float r, float g, float b, co
     }
 }
 
+/* ColorConverter<Src,Dst>::op colorconvert.cc:136-152, force-inlined per (source, destination) format like the
+ * reference's 8 x 8 template dispatch (colorconvert.cc:154-188) */
+static inline __attribute__((always_inline)) void convert_body(const oracle_image *src, const oracle_image *dst, float r, float g,
+                                                               float b, const int sp, const int dp) {
+    const int sb = k_bytes[sp], db = k_bytes[dp];
+    const int sc = k_channels[sp], dc = k_channels[dp];
+    float srcpack[4], dstpack[4];
+    for (int i = 0; i < src->height; ++i) { /* colorconvert.cc:143-150 */
+        char *s = img_row(src, i), *d = img_row(dst, i);
+        for (int j = 0; j < src->width; ++j, s += sb, d += db) {
+            unpack_px(sp, s, srcpack);
+            channel_convert(sc, dc, r, g, b, srcpack, dstpack);
+            pack_px(dp, dstpack, d);
+        }
+    }
+}
+#define ORACLE_CONVERT_SRC(SP)                                                                                         \
+    static __attribute__((noinline)) void convert_src_##SP(const oracle_image *src, const oracle_image *dst, float r, \
+                                                           float g, float b) {                                        \
+        switch (dst->pixel) { /* doSrcColorConvert colorconvert.cc:154-169 */                                          \
+        case 0: convert_body(src, dst, r, g, b, SP, 0); break;                                                        \
+        case 1: convert_body(src, dst, r, g, b, SP, 1); break;                                                        \
+        case 2: convert_body(src, dst, r, g, b, SP, 2); break;                                                        \
+        case 3: convert_body(src, dst, r, g, b, SP, 3); break;                                                        \
+        case 4: convert_body(src, dst, r, g, b, SP, 4); break;                                                        \
+        case 5: convert_body(src, dst, r, g, b, SP, 5); break;                                                        \
+        case 6: convert_body(src, dst, r, g, b, SP, 6); break;                                                        \
+        case 7: convert_body(src, dst, r, g, b, SP, 7); break;                                                        \
+        }                                                                                                             \
+    }
+ORACLE_CONVERT_SRC(0) ORACLE_CONVERT_SRC(1) ORACLE_CONVERT_SRC(2) ORACLE_CONVERT_SRC(3)
+ORACLE_CONVERT_SRC(4) ORACLE_CONVERT_SRC(5) ORACLE_CONVERT_SRC(6) ORACLE_CONVERT_SRC(7)
+#undef ORACLE_CONVERT_SRC
+
 int oracle_color_convert(const oracle_image *src, const oracle_image *dst, float r, float g, float b) {
     if (src->width != dst->width || src->height != dst->height) return -5; /* asserts colorconvert.cc:138-139 */
     if (src->pixel < 0 || src->pixel > 7 || dst->pixel < 0 || dst->pixel > 7) return -1;
@@ -318,16 +379,15 @@ int oracle_color_convert(const oracle_image *src, const oracle_image *dst, float
         for (int h = 0; h < src->height; ++h) memcpy(img_row(dst, h), img_row(src, h), (size_t)rw);
         return 0;
     }
-    const int sb = k_bytes[src->pixel], db = k_bytes[dst->pixel];
-    const int sc = k_channels[src->pixel], dc = k_channels[dst->pixel];
-    float srcpack[4], dstpack[4];
-    for (int i = 0; i < src->height; ++i) { /* ColorConverter::op colorconvert.cc:143-150 */
-        char *s = img_row(src, i), *d = img_row(dst, i);
-        for (int j = 0; j < src->width; ++j, s += sb, d += db) {
-            unpack_px(src->pixel, s, srcpack);
-            channel_convert(sc, dc, r, g, b, srcpack, dstpack);
-            pack_px(dst->pixel, dstpack, d);
-        }
+    switch (src->pixel) { /* doColorConvert colorconvert.cc:176-187 */
+    case 0: convert_src_0(src, dst, r, g, b); break;
+    case 1: convert_src_1(src, dst, r, g, b); break;
+    case 2: convert_src_2(src, dst, r, g, b); break;
+    case 3: convert_src_3(src, dst, r, g, b); break;
+    case 4: convert_src_4(src, dst, r, g, b); break;
+    case 5: convert_src_5(src, dst, r, g, b); break;
+    case 6: convert_src_6(src, dst, r, g, b); break;
+    case 7: convert_src_7(src, dst, r, g, b); break;
     }
     return 0;
 }

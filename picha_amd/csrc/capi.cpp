@@ -7,6 +7,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <climits>
 #include <cstring>
 #include <deque>
@@ -28,6 +29,7 @@ namespace {
 // ---- error plumbing ----------------------------------------------------------------------------
 thread_local std::string g_last_error;
 thread_local const char *g_last_kernel = "";
+thread_local char g_chain_name[288];  // "first + second" of a chained convert + resize
 
 int fail(int status, const char *fmt, ...) {
     char buf[512];
@@ -84,6 +86,11 @@ long g_opt_sym = 0;         // symmetric-table streaming kernel (kernels_sym.hip
 long g_opt_block_waves = 0; // its waves per workgroup (0 auto)
 long g_opt_acc_p2 = 0;      // accumulator kernel with two outputs per lane: 0 auto (measured table), 1 whenever possible, 2 never
 long g_opt_sym_sync = 0;    // 1: a barrier per step keeps the waves of a workgroup in lockstep
+long g_opt_work = 0;        // sym / accumulator kernels, work items: 0 auto, 1 explicit item list (one workgroup per item, short chunks last),
+                            // 2 persistent launch (resident workgroups pull items from per-XCD atomic queues), 3 plain 3-D grid
+long g_opt_work_tail = 120; // per mille of every XCD's sub-list that is cut into short row chunks
+long g_opt_work_tail_div = 4;  // ... short chunk = long chunk / this
+long g_opt_xch = 0;         // symmetric-table kernel, neighbour exchange (a lane loads only its own pixels): 0 auto, 1 wherever instantiated, 2 never
 
 // ---- per-device state ---------------------------------------------------------------------------
 struct DeviceAxis {
@@ -186,6 +193,11 @@ struct DeviceCtx {
     TempBuf chain;       // intermediate images of picha_hip_convert_resize_device
     std::mutex results_mu;
     TempBuf results;     // picha_hip_image_compare_device: per-image sums (device + pinned mirror)
+    // work-item lists (kernels.h, WorkList) per (images, output rows, strip blocks, long chunk, short chunk, tail share), and
+    // one set of queue counters per stream (launches on a stream are ordered, so they can share it); both under `mu`
+    struct ItemList { void *blob = nullptr; const int4 *items = nullptr; int per_xcd = 0; };
+    std::map<std::tuple<int, int, int, int, int, int>, ItemList> item_lists;
+    std::map<hipStream_t, unsigned *> queues;
 };
 
 std::mutex g_ctx_mu;
@@ -332,7 +344,7 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
     const int dst = t.dst_size, T = t.taps;
     const int groups = (dst + per_lane - 1) / per_lane;
     const int stride = groups * per_lane;
-    std::vector<int32_t> left(groups);
+    std::vector<int32_t> left(groups), gbase(groups);
     std::vector<float> weight((size_t)taps * stride, 0.0f);
     const float inv = is16 ? 1.0f / 65535.0f : 1.0f / 255.0f;
     bool ok = taps >= T || per_lane > 1;
@@ -359,6 +371,7 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
         base = std::min(base, max_left);
         if (bytespan_bpp || window_align > 1) base -= ((base % align_px) + align_px) % align_px;
         left[g] = uniform_base ? l0 : base;
+        gbase[g] = base;
         for (int q = 0; q < per_lane && g * per_lane + q < dst; ++q) {
             const int i = g * per_lane + q;
             const int first = t.left[i] - (base + step * q);  // >= 0 by construction
@@ -371,13 +384,13 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
     }
     xt.ok = ok;
     xt.l0 = uniform_base ? l0 : 0;
-    if (ok && !bytespan_bpp && !uniform_base && taps <= 15 && dst >= 4) {
+    if (ok && !bytespan_bpp && taps <= 15 && dst >= 4) {
         int xb = INT32_MAX;
         for (int i = 0; i < dst; ++i) xb = std::min(xb, t.left[i] - step * i);
         const int mid = dst / 2;
         auto wbits = [&](int i, int j) { int32_t b; memcpy(&b, &weight[(size_t)j * stride + i], 4); return b; };
         auto is_canon = [&](int i) {
-            if (left[i / per_lane] + step * (i % per_lane) != step * i + xb) return false;
+            if (gbase[i / per_lane] + step * (i % per_lane) != step * i + xb) return false;
             for (int j = 0; j < taps; ++j) if (wbits(i, j) != wbits(mid, j)) return false;
             return true;
         };
@@ -607,6 +620,23 @@ bool acc_p2_preferred(int pixel, int step, int taps, int fma) {
     return false;
 }
 
+// where the neighbour-exchange form of the symmetric-table kernel is the default (measured, profiles/r03_ab_xch*.txt)
+bool sym_xch_preferred(int pixel, int step, int taps, int per_lane, int fma) {
+    (void)pixel; (void)step; (void)taps; (void)per_lane; (void)fma;
+    return false;
+}
+
+// default work mode of a launch with `n` images, `col_waves` waves per output row and `chunks` row chunks (0 = plain grid)
+int work_default(int n, long long col_waves, int chunks) {
+    (void)n; (void)col_waves; (void)chunks;
+    return 0;
+}
+
+bool acc_xch_preferred(int pixel, int step, int taps, int per_lane, int fma) {
+    (void)pixel; (void)step; (void)taps; (void)per_lane; (void)fma;
+    return false;
+}
+
 // Outputs per lane for which resize_sym_kernel beats the general streaming / accumulator kernels by >= 2 % (0: it does not):
 // interleaved survey of all 8 formats x {2x: 3, 5, 7 taps; 3x: 8, 12; 4x: 11, 15} on 64 x 4K images, both numerics flavours
 // (scripts/survey_sym.py, profiles/r02_survey_sym_exact.txt, r02_survey_sym_fma.txt).
@@ -624,6 +654,75 @@ int sym_preferred_per_lane(int pixel, int step, int taps, int fma) {
     for (const E *e = tabs[pixel]; e->step; ++e)
         if (e->step == step && e->taps == taps) return fma ? e->fma : e->exact;
     return 0;
+}
+
+// Work items of a launch (kernels.h, WorkList).  Units = (image, long row chunk) in batch order, dealt to the 8 XCDs in
+// contiguous eighths; inside an eighth the last `tail_pm` per mille of the units are cut into short chunks, and every
+// (image, rows) piece becomes `nsb` consecutive items, one per column-strip block.  Sub-lists are padded to equal length
+// with empty items.  Built once per key, then a lookup.
+int get_items(DeviceCtx *ctx, int n, int dst_h, int nsb, int rows_long, int rows_short, int tail_pm, const DeviceCtx::ItemList **out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto key = std::make_tuple(n, dst_h, nsb, rows_long, rows_short, tail_pm);
+    auto it = ctx->item_lists.find(key);
+    if (it != ctx->item_lists.end()) { *out = &it->second; return PICHA_OK; }
+    if (ctx->item_lists.size() >= 64) {  // bounded: drop everything (hipFree waits for the kernels still reading them)
+        for (auto &kv : ctx->item_lists) (void)hipFree(kv.second.blob);
+        ctx->item_lists.clear();
+    }
+    struct Unit { int img, y0, y1; };
+    std::vector<Unit> units;
+    const int chunks = (dst_h + rows_long - 1) / rows_long;
+    const int rl = (dst_h + chunks - 1) / chunks;
+    for (int i = 0; i < n; ++i)
+        for (int y = 0; y < dst_h; y += rl) units.push_back({i, y, std::min(dst_h, y + rl)});
+    std::vector<int4> lists[8];
+    const size_t U = units.size();
+    for (int x = 0; x < 8; ++x) {
+        const size_t lo = U * x / 8, hi = U * (x + 1) / 8;
+        const size_t tail = std::min<size_t>(hi - lo, ((hi - lo) * (size_t)tail_pm + 999) / 1000);
+        for (size_t k = lo; k < hi; ++k) {
+            const Unit &u = units[k];
+            const int step = (k >= hi - tail) ? std::max(1, rows_short) : (u.y1 - u.y0);
+            // equal short chunks: ceil split
+            const int pieces = (u.y1 - u.y0 + step - 1) / step;
+            const int rows = (u.y1 - u.y0 + pieces - 1) / pieces;
+            for (int y = u.y0; y < u.y1; y += rows)
+                for (int b = 0; b < nsb; ++b) lists[x].push_back(make_int4(b, y, std::min(u.y1, y + rows), u.img));
+        }
+    }
+    size_t per = 1;
+    for (auto &l : lists) per = std::max(per, l.size());
+    std::vector<int4> flat(per * 8, make_int4(0, 0, 0, 0));
+    for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), flat.begin() + (long)(per * x));
+    DeviceCtx::ItemList il;
+    HIP_TRY(hipMalloc(&il.blob, flat.size() * sizeof(int4)));
+    HIP_TRY(hipMemcpy(il.blob, flat.data(), flat.size() * sizeof(int4), hipMemcpyHostToDevice));
+    il.items = static_cast<const int4 *>(il.blob);
+    il.per_xcd = (int)per;
+    auto ins = ctx->item_lists.emplace(key, il);
+    *out = &ins.first->second;
+    return PICHA_OK;
+}
+
+// the stream's queue counters, zeroed in stream order for the launch that follows
+int get_queue(DeviceCtx *ctx, hipStream_t s, unsigned **out) {
+    unsigned *q = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->mu);
+        auto it = ctx->queues.find(s);
+        if (it != ctx->queues.end()) q = it->second;
+        else {
+            if (ctx->queues.size() >= 256) {
+                for (auto &kv : ctx->queues) (void)hipFree(kv.second);
+                ctx->queues.clear();
+            }
+            HIP_TRY(hipMalloc((void **)&q, 64));
+            ctx->queues[s] = q;
+        }
+    }
+    HIP_TRY(hipMemsetAsync(q, 0, 64, s));
+    *out = q;
+    return PICHA_OK;
 }
 
 // Column strips of the row-staged kernel: strip b = groups [256 b, 256 b + 256); it stages the source pixels from
@@ -794,7 +893,11 @@ int rows_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, i
         q.n_images = m;
         if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
         else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
-        HIP_TRY(launch_resize_rows_kernel(variant, q, s, &g_last_kernel));
+        const hipError_t e = launch_resize_rows_kernel(variant, q, s, &g_last_kernel);
+        if (e != hipSuccess) {
+            if (tab.used) (void)temp_release(ctx->tables, s);
+            return fail(PICHA_ERR_HIP, "row-staged resize launch failed: %s", hipGetErrorString(e));
+        }
         done += m;
     }
     *used = true;
@@ -824,9 +927,12 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (rc) return rc;
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
-    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_bw, opt_sym_sync, opt_acc_p2;
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_bw, opt_sym_sync, opt_acc_p2, opt_xch;
+    long opt_work, opt_work_tail, opt_work_tail_div;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
+        opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
+        opt_xch = g_opt_xch;
         opt_sym = g_opt_sym; opt_bw = g_opt_block_waves; opt_sym_sync = g_opt_sym_sync; opt_acc_p2 = g_opt_acc_p2;
         opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
         opt_rot = g_opt_stream_rot;
@@ -900,7 +1006,8 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         // coalesced loads, but measured 2-4 % SLOWER than the plain variant on cfg2 (the kernel is bound by
         // mixed read/write HBM traffic, not by the conversions it saves): opt-in only ("dpp" = 1)
         // fills the parameters, sizes the row chunks and launches (resize_stream_kernel family or resize_sym_kernel)
-        auto launch_stream = [&](int pl, const DeviceAxis::XTable *cx, const DeviceAxis::YStream *cy, int rot, bool dpp, bool sym, int bw) -> int {
+        auto launch_stream = [&](int pl, const DeviceAxis::XTable *cx, const DeviceAxis::YStream *cy, int rot, bool dpp, bool sym, int bw,
+                                 bool xch = false) -> int {
             StreamParams p{};
             long long sp = 0, dp = 0;
             TablePair tab;
@@ -931,6 +1038,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 p.cx0 = cx->c0; p.cx1 = cx->c1; p.x_base = cx->xbase;
                 p.block_waves = bw;
                 p.sync_steps = opt_sym_sync == 1 ? 1 : 0;
+                p.xch = xch ? 1 : 0;
             }
             const long long col_waves = (cx->groups + 63) / 64;
             // row chunks: at least ~32 K waves per launch, chunks of >= 16 output rows.  Every chunk re-reads and
@@ -950,6 +1058,31 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
             p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
             p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
+            // work items (sym kernel): explicit list with short chunks last, optionally pulled by persistent workgroups
+            const int work_mode = !sym || p.sync_steps ? 0 : opt_work == 3 ? 0 : opt_work > 0 ? (int)opt_work : work_default(n, col_waves, p.n_chunks);
+            if (work_mode) {
+                const int nsb = (int)((cx->groups + 64 * bw - 1) / (64 * bw));
+                const DeviceCtx::ItemList *il = nullptr;
+                int rc2 = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(4, p.rows_per_chunk / (int)opt_work_tail_div), (int)opt_work_tail, &il);
+                if (rc2) return rc2;
+                p.n_images = n;
+                p.work.items = il->items; p.work.items_per_xcd = il->per_xcd;
+                if (work_mode == 2) {
+                    const int resident = sym_kernel_resident_blocks(pixel, p);
+                    if (resident > 0 && (long long)il->per_xcd * 8 > 2LL * resident) {
+                        rc2 = get_queue(ctx, s, &p.work.queue);
+                        if (rc2) return rc2;
+                        p.n_chunks = resident / 8 * 8;
+                    }
+                }
+                const hipError_t e = launch_resize_sym_kernel(pixel, p, s, &g_last_kernel);
+                if (e != hipSuccess) {
+                    if (tab.used) (void)temp_release(ctx->tables, s);
+                    return fail(PICHA_ERR_HIP, "streaming resize launch failed: %s", hipGetErrorString(e));
+                }
+                if (tab.used) return temp_release(ctx->tables, s);
+                return PICHA_OK;
+            }
             int done = 0;
             while (done < n) {
                 const int m = std::min(n - done, 65535);
@@ -957,7 +1090,11 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 q.n_images = m;
                 if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
                 else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
-                HIP_TRY(sym ? launch_resize_sym_kernel(pixel, q, s, &g_last_kernel) : launch_resize_stream_kernel(pixel, q, s, &g_last_kernel));
+                const hipError_t e = sym ? launch_resize_sym_kernel(pixel, q, s, &g_last_kernel) : launch_resize_stream_kernel(pixel, q, s, &g_last_kernel);
+                if (e != hipSuccess) {
+                    if (tab.used) (void)temp_release(ctx->tables, s);
+                    return fail(PICHA_ERR_HIP, "streaming resize launch failed: %s", hipGetErrorString(e));
+                }
                 done += m;
             }
             if (tab.used) return temp_release(ctx->tables, s);
@@ -973,10 +1110,22 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 if (pl == 0) break;
                 if (opt_per_lane > 0 && pl != opt_per_lane) continue;
                 if (subdword && ((pl * kBytes[pixel]) % 4 != 0 || !dst_dword_rows)) continue;
-                if (!sym_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps)) continue;
+                // neighbour exchange (kernels_sym.hip, XchCfg): dword-sized pixels, uniform-base x table whose windows start
+                // (taps - step - 1) / 2 pixels before the lane's own pixels
+                bool xch = opt_xch != 2 && !subdword && sym_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps, 1) &&
+                           (opt_xch == 1 || sym_xch_preferred(pixel, sx, ax->host.taps, pl, fma));
+                if (!xch && !sym_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps)) continue;
                 const DeviceAxis::XTable *cx = nullptr;
                 const DeviceAxis::YStream *cy = nullptr;
-                rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, xw_mode, is16, &cx);
+                if (xch) {
+                    rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, xw_mode, is16, &cx, 0, true);
+                    if (rc) return rc;
+                    if (!cx->ok || !cx->sym || cx->xbase != -((ax->host.taps - sx - 1) / 2)) {
+                        xch = false;
+                        if (!sym_kernel_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps)) continue;
+                    }
+                }
+                if (!xch) rc = get_xtable(ctx, ax, pl, sx, ax->host.taps, xw_mode, is16, &cx);
                 if (rc) return rc;
                 rc = get_ystream(ctx, ay, sy, ay->host.taps, &cy);
                 if (rc) return rc;
@@ -985,7 +1134,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 // waves per workgroup: small groups backfill the SIMDs sooner (reference arithmetic: VALU + latency bound,
                 // -3..5 %); the memory-bound fma flavour prefers 4 (neighbouring strips share their edge lines in one L1)
                 const int bw = opt_bw > 0 ? (int)std::min<long>(opt_bw, 4) : (fma ? 4 : 2);
-                return launch_stream(pl, cx, cy, 0, false, true, bw);
+                return launch_stream(pl, cx, cy, 0, false, true, bw, xch);
             }
         }
         bool want_dpp = opt_dpp == 1 && stream_dpp_supported(pixel, sx, ax->host.taps, sy, ay->host.taps);
@@ -1032,6 +1181,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     const DeviceAxis::YRows *yr = nullptr;
     const DeviceAxis::XTable *xa = nullptr;
     int nacc = 0, acc_per_lane = 1, acc_x_step = 1;
+    bool acc_xch = false;
     constexpr int kAccMinRing = 1;  // measured faster than the span kernel for every ring size it was tried on (profiles/r01_survey_acc_vs_span.txt)
     int ataps = fused_x_bucket(ax->host.taps, pixel, true);  // the accumulator kernel's own (finer) x bucket
     const bool acc_long = ataps == 0 && ax->host.taps > 36 && ax->host.taps <= 128;
@@ -1051,7 +1201,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         // two outputs per lane (r02): the union of both windows is loaded and converted once; option "acc_p2": 0 auto (where
         // acc_p2_preferred says it was measured faster), 1 whenever a shape exists, 2 never
         int acc_pl = 1, acc_step = 1;
-        if (yr && !acc_long && opt_acc_p2 != 2 && (opt_per_lane == 0 || opt_per_lane == 2)) {
+        if (yr && !acc_long && opt_acc_p2 != 2 && opt_xch != 1 && (opt_per_lane == 0 || opt_per_lane == 2)) {
             const int st = (int)std::floor((double)s0.width / d0.width);
             static const int shapes[][2] = {{2, 8}, {3, 12}, {4, 12}, {4, 16}};
             for (auto &e : shapes) {
@@ -1061,6 +1211,21 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 rc = get_xtable(ctx, ax, 2, e[0], e[1], xw_mode, is16, &cx);
                 if (rc) return rc;
                 if (cx->ok) { xa = cx; acc_pl = 2; acc_step = e[0]; ataps = e[1]; break; }
+            }
+        }
+        // neighbour-exchange form (r03): integer steps of dword-sized pixels; a lane loads only its own step * P pixels and takes
+        // the rest of its window from the two neighbouring lanes (kernels_impl.inc, XchCfg).  Option "xch": 0 auto, 1 wherever
+        // an instantiation exists, 2 never
+        if (yr && !acc_long && opt_xch != 2 && kBytes[pixel] % 4 == 0 && s0.width % d0.width == 0) {
+            const int st = s0.width / d0.width, T = ax->host.taps;
+            for (int pl : {2, 4}) {
+                if (opt_per_lane > 0 && pl != opt_per_lane) continue;
+                if (!acc_xch_supported(pixel, pl, st, T, nacc)) continue;
+                if (opt_xch == 0 && !acc_xch_preferred(pixel, st, T, pl, fma)) continue;
+                const DeviceAxis::XTable *cx = nullptr;
+                rc = get_xtable(ctx, ax, pl, st, T, xw_mode, is16, &cx, 0, true);
+                if (rc) return rc;
+                if (cx->ok && cx->l0 == -((T - st - 1) / 2)) { xa = cx; acc_pl = pl; acc_step = st; ataps = T; acc_xch = true; break; }
             }
         }
         if (yr && acc_pl == 1) {
@@ -1112,7 +1277,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         p.y_taps = ay->host.taps; p.y_pad = ay->y_pad;
         p.ring_slots = ring;
         p.xcd_remap = opt_xcd == 1 ? 1 : 0;
-        if (use_acc) { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; p.x_per_lane = acc_per_lane; p.x_step = acc_x_step; }
+        if (use_acc) { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; p.x_per_lane = acc_per_lane; p.x_step = acc_x_step; p.xch = acc_xch ? 1 : 0; }
         // row chunks: enough waves to fill 256 CUs several times over (~32 K), but every chunk re-resamples the `ring`
         // source rows above its first output: keep that halo under ~6 % of the chunk's own source rows unless the
         // launch would then have fewer than ~8 K waves (4K -> 512x288 thumbnails: 18 -> 6 chunks, -5 %)
@@ -1128,6 +1293,30 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
         p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
         p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
+        // work items (accumulator kernel, windows up to 36 taps)
+        const int work_mode = !use_acc || ktaps > 36 ? 0 : opt_work == 3 ? 0 : opt_work > 0 ? (int)opt_work : work_default(n, col_waves, p.n_chunks);
+        if (work_mode) {
+            const int nsb = (xt->groups + 255) / 256;
+            const DeviceCtx::ItemList *il = nullptr;
+            rc = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(4, p.rows_per_chunk / (int)opt_work_tail_div), (int)opt_work_tail, &il);
+            if (rc) return rc;
+            p.work.items = il->items; p.work.items_per_xcd = il->per_xcd;
+            if (work_mode == 2) {
+                const int resident = acc_kernel_resident_blocks(pixel, p);
+                if (resident > 0 && (long long)il->per_xcd * 8 > 2LL * resident) {
+                    rc = get_queue(ctx, s, &p.work.queue);
+                    if (rc) return rc;
+                    p.n_chunks = resident / 8 * 8;
+                }
+            }
+            const hipError_t e = launch_resize_acc(pixel, p, s, &g_last_kernel);
+            if (e != hipSuccess) {
+                if (tab.used) (void)temp_release(ctx->tables, s);
+                return fail(PICHA_ERR_HIP, "fused resize launch failed: %s", hipGetErrorString(e));
+            }
+            if (tab.used) return temp_release(ctx->tables, s);
+            return PICHA_OK;
+        }
         // grid.z limit
         int done = 0;
         while (done < n) {
@@ -1136,7 +1325,11 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             q.n_images = m;
             if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
             else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
-            HIP_TRY(use_acc ? launch_resize_acc(pixel, q, s, &g_last_kernel) : launch_resize_fused(pixel, q, s, &g_last_kernel));
+            const hipError_t e = use_acc ? launch_resize_acc(pixel, q, s, &g_last_kernel) : launch_resize_fused(pixel, q, s, &g_last_kernel);
+            if (e != hipSuccess) {
+                if (tab.used) (void)temp_release(ctx->tables, s);
+                return fail(PICHA_ERR_HIP, "fused resize launch failed: %s", hipGetErrorString(e));
+            }
             done += m;
         }
         if (tab.used) return temp_release(ctx->tables, s);
@@ -1194,6 +1387,7 @@ int convert_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst
     p.src_stride = s0.stride; p.dst_stride = d0.stride;
     p.width = s0.width; p.height = s0.height;
     p.r = r; p.g = g; p.b = b;
+    { std::lock_guard<std::mutex> lk(g_opt_mu); p.cc_mode = (int)g_opt_cc_mode; }  // one value for the whole launch
     {   // the wide (16-byte access) kernel needs dword-aligned rows on both sides and 32-bit offsets inside an image
         const size_t sspan = image_span(s0), dspan = image_span(d0);
         bool wide = sspan < (1ull << 32) - 64 && dspan < (1ull << 32) - 64;
@@ -1209,7 +1403,11 @@ int convert_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst
         q.n_images = m;
         if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
         else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
-        HIP_TRY(launch_color_convert(s0.pixel, d0.pixel, q, s));
+        const hipError_t e = launch_color_convert(s0.pixel, d0.pixel, q, s, &g_last_kernel);
+        if (e != hipSuccess) {
+            if (tab.used) (void)temp_release(ctx->tables, s);  // the table upload and earlier launches are still in flight
+            return fail(PICHA_ERR_HIP, "colour-convert launch failed: %s", hipGetErrorString(e));
+        }
         done += m;
     }
     if (tab.used) return temp_release(ctx->tables, s);
@@ -1217,16 +1415,27 @@ int convert_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst
 }
 
 // Host-pointer entry points: stream + pinned staging buffer + device arena travel together as one "lane", leased from
-// a bounded per-device pool for the duration of a call.  (They used to be thread_local and were never freed: a service
-// that spawns a thread per request leaked ~50 MB pinned + ~50 MB HBM per dead thread.)  Memory is now bounded by the
-// number of CONCURRENT callers; lanes beyond kMaxIdleLanes are destroyed when they come back.
+// a per-device pool for the duration of a call.  (They used to be thread_local and were never freed: a service
+// that spawns a thread per request leaked ~50 MB pinned + ~50 MB HBM per dead thread.)  The pool keeps as many idle lanes
+// as callers were ever inside a call at once (at least kMinIdleLanes) as long as their memory stays under a byte budget:
+// a steady pool of N worker threads therefore never creates or frees a lane after warm-up — hipFree / hipHostFree are
+// device-wide synchronisations and would stall the async dispatchers' streams.  Lanes beyond that (a burst larger than
+// anything seen before, or over the budget) are retired lazily: they are parked and destroyed by a later acquire() once
+// they have been idle for kLaneIdleSeconds, never on a call's return path.
 struct HostLane {
     hipStream_t s = nullptr;
     uint8_t *pinned = nullptr; size_t pinned_cap = 0;
     uint8_t *arena = nullptr;  size_t arena_cap = 0;
+    std::chrono::steady_clock::time_point idle_since;
 };
-struct LanePool { std::mutex mu; std::vector<HostLane *> idle; };
-constexpr size_t kMaxIdleLanes = 4;
+struct LanePool {
+    std::mutex mu;
+    std::vector<HostLane *> idle;  // most recently used at the back
+    size_t in_use = 0, peak_in_use = 0;
+};
+constexpr size_t kMinIdleLanes = 16;
+constexpr size_t kLaneBudgetBytes = (size_t)4 << 30;  // pinned bytes (and as many device bytes) the idle lanes may hold
+constexpr int kLaneIdleSeconds = 10;
 std::mutex g_lane_mu;
 std::map<int, LanePool *> g_lane_pools;  // never destroyed: static destruction order vs. the HIP runtime
 
@@ -1242,29 +1451,52 @@ void lane_destroy(HostLane *l) {  // errors ignored: also runs at teardown
     if (l->arena) (void)hipFree(l->arena);
     delete l;
 }
+// lanes the pool no longer wants (caller holds pool->mu): idle for a while AND surplus to the peak concurrency or the budget
+void lane_collect_surplus(LanePool *pool, std::vector<HostLane *> *out) {
+    const auto now = std::chrono::steady_clock::now();
+    const size_t keep = std::max(kMinIdleLanes, pool->peak_in_use);
+    size_t bytes = 0;
+    for (HostLane *l : pool->idle) bytes += l->pinned_cap;
+    size_t i = 0;  // oldest first
+    while (i < pool->idle.size() && (pool->idle.size() + pool->in_use > keep || bytes > kLaneBudgetBytes)) {
+        HostLane *l = pool->idle[i];
+        if (std::chrono::duration_cast<std::chrono::seconds>(now - l->idle_since).count() < kLaneIdleSeconds) { ++i; continue; }
+        bytes -= l->pinned_cap;
+        out->push_back(l);
+        pool->idle.erase(pool->idle.begin() + (long)i);
+    }
+}
 struct LaneLease {
     int dev = -1;
     HostLane *lane = nullptr;
     ~LaneLease() {
         if (!lane) return;
         LanePool *pool = lane_pool(dev);
-        {
-            std::lock_guard<std::mutex> lk(pool->mu);
-            if (pool->idle.size() < kMaxIdleLanes) { pool->idle.push_back(lane); lane = nullptr; }
-        }
-        if (lane) lane_destroy(lane);  // the stream is idle: every call ends with hipStreamSynchronize
+        lane->idle_since = std::chrono::steady_clock::now();
+        std::lock_guard<std::mutex> lk(pool->mu);  // nothing is freed here: see lane_collect_surplus
+        pool->idle.push_back(lane);
+        --pool->in_use;
     }
     int acquire(int device) {
         dev = device;
         LanePool *pool = lane_pool(dev);
+        std::vector<HostLane *> surplus;
         {
             std::lock_guard<std::mutex> lk(pool->mu);
             if (!pool->idle.empty()) { lane = pool->idle.back(); pool->idle.pop_back(); }
+            ++pool->in_use;
+            pool->peak_in_use = std::max(pool->peak_in_use, pool->in_use);
+            lane_collect_surplus(pool, &surplus);
         }
+        for (HostLane *l : surplus) lane_destroy(l);  // rare: only lanes idle for kLaneIdleSeconds beyond what the pool keeps
         if (!lane) {
             lane = new HostLane;
             hipError_t e = hipStreamCreateWithFlags(&lane->s, hipStreamNonBlocking);
-            if (e != hipSuccess) { delete lane; lane = nullptr; return fail(PICHA_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e)); }
+            if (e != hipSuccess) {
+                delete lane; lane = nullptr;
+                { std::lock_guard<std::mutex> lk(pool->mu); --pool->in_use; }
+                return fail(PICHA_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
+            }
         }
         return PICHA_OK;
     }
@@ -1486,9 +1718,13 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "sym") == 0) { g_opt_sym = value; return PICHA_OK; }
     if (strcmp(key, "rows") == 0) { g_opt_rows = value; return PICHA_OK; }
     if (strcmp(key, "fuse") == 0) { g_opt_fuse = value; return PICHA_OK; }
-    if (strcmp(key, "cc_mode") == 0) { g_opt_cc_mode = value; set_color_convert_mode((int)value); return PICHA_OK; }
+    if (strcmp(key, "cc_mode") == 0) { g_opt_cc_mode = value; return PICHA_OK; }
     if (strcmp(key, "block_waves") == 0) { g_opt_block_waves = value; return PICHA_OK; }
     if (strcmp(key, "sym_sync") == 0) { g_opt_sym_sync = value; return PICHA_OK; }
+    if (strcmp(key, "xch") == 0) { g_opt_xch = value; return PICHA_OK; }
+    if (strcmp(key, "work") == 0) { g_opt_work = value; return PICHA_OK; }
+    if (strcmp(key, "work_tail") == 0) { g_opt_work_tail = value; return PICHA_OK; }
+    if (strcmp(key, "work_tail_div") == 0) { g_opt_work_tail_div = value; return PICHA_OK; }
     if (strcmp(key, "acc_p2") == 0) { g_opt_acc_p2 = value; return PICHA_OK; }
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
     if (strcmp(key, "acc") == 0) { g_opt_acc = value; return PICHA_OK; }
@@ -1512,6 +1748,10 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "cc_mode") == 0) return g_opt_cc_mode;
     if (strcmp(key, "block_waves") == 0) return g_opt_block_waves;
     if (strcmp(key, "sym_sync") == 0) return g_opt_sym_sync;
+    if (strcmp(key, "xch") == 0) return g_opt_xch;
+    if (strcmp(key, "work") == 0) return g_opt_work;
+    if (strcmp(key, "work_tail") == 0) return g_opt_work_tail;
+    if (strcmp(key, "work_tail_div") == 0) return g_opt_work_tail_div;
     if (strcmp(key, "acc_p2") == 0) return g_opt_acc_p2;
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
     if (strcmp(key, "acc") == 0) return g_opt_acc;
@@ -1612,9 +1852,14 @@ int picha_hip_convert_resize_device(int n, const picha_image *src, const picha_i
         } else if ([&] {  // colour convert fused into the row-staged resize: the intermediate never exists in HBM
                        bool used = false;
                        rc = PICHA_OK;
-                       long fuse;
-                       { std::lock_guard<std::mutex> lk(g_opt_mu); fuse = g_opt_fuse; }
-                       if (order == PICHA_CONVERT_THEN_RESIZE && fuse != 2) rc = rows_group(ctx, src + i, dst + i, j - i, filter, filter_scale, r, g, b, s, &used);
+                       long fuse, path;
+                       { std::lock_guard<std::mutex> lk(g_opt_mu); fuse = g_opt_fuse; path = g_opt_path; }
+                       // like resize_group: a forced kernel family ("path" 1..4) is honoured, 5 means this kernel or an error
+                       if (order == PICHA_CONVERT_THEN_RESIZE && fuse != 2 && (path == 0 || path == 5)) {
+                           rc = rows_group(ctx, src + i, dst + i, j - i, filter, filter_scale, r, g, b, s, &used);
+                           if (rc == PICHA_OK && !used && path == 5)
+                               rc = fail(PICHA_ERR_ARGUMENT, "row-staged kernel forced but unsupported for this chain");
+                       }
                        return rc != PICHA_OK || used;
                    }()) {
             // done (or failed) in the fused kernel
@@ -1636,12 +1881,19 @@ int picha_hip_convert_resize_device(int n, const picha_image *src, const picha_i
             // slice by slice on one in-order stream; the buffer is reused by the next slice
             for (int k = i; k < j && rc == PICHA_OK; k += slice) {
                 const int m = std::min(slice, j - k);
+                std::string first;
                 if (order == PICHA_CONVERT_THEN_RESIZE) {
                     rc = convert_group(ctx, src + k, mids.data(), m, r, g, b, s);
+                    first = g_last_kernel;
                     if (rc == PICHA_OK) rc = resize_group(ctx, mids.data(), dst + k, m, filter, filter_scale, s);
                 } else {
                     rc = resize_group(ctx, src + k, mids.data(), m, filter, filter_scale, s);
+                    first = g_last_kernel;
                     if (rc == PICHA_OK) rc = convert_group(ctx, mids.data(), dst + k, m, r, g, b, s);
+                }
+                if (rc == PICHA_OK) {  // two kernels ran: picha_hip_last_kernel names both
+                    snprintf(g_chain_name, sizeof g_chain_name, "%s + %s", first.c_str(), g_last_kernel);
+                    g_last_kernel = g_chain_name;
                 }
             }
             int rc2 = temp_release(ctx->chain, s);

@@ -333,7 +333,7 @@ int submit(int kind, int order, const picha_image *src, const picha_image *dst, 
     // images, no exchange between devices.  Default (0): the caller's current device only.
     // "async_virtual_devices" = 1 lets N exceed the visible device count: dispatcher k then runs on physical device
     // k mod visible — on a one-GPU box this exercises the spread itself (several dispatchers, each with its own streams
-    // and staging, fed round-robin) although they share the card.
+    // and staging, fed round-robin) although they share the card.  At most 8 dispatchers per visible device.
     const long want = picha_hip_get_option("async_devices");
     int slot = dev;  // dispatcher index; physical device = slot mod visible
     int phys = dev;
@@ -341,7 +341,8 @@ int submit(int kind, int order, const picha_image *src, const picha_image *dst, 
         static std::atomic<unsigned> next{0};
         int ndev = 1;
         if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) ndev = 1;
-        const long n = picha_hip_get_option("async_virtual_devices") > 0 ? want : std::min<long>(want, ndev);
+        // virtual dispatchers are bounded: each one owns two threads, three streams and pinned staging
+        const long n = picha_hip_get_option("async_virtual_devices") > 0 ? std::min<long>(want, 8L * ndev) : std::min<long>(want, ndev);
         slot = (int)(next.fetch_add(1) % (unsigned)n);
         phys = slot % ndev;
     }

@@ -24,10 +24,25 @@ struct ConvertParams {
     // one image spans less than 4 GB; src_bytes / dst_bytes = bytes of ONE image (buffer descriptor range)
     int wide_ok;
     unsigned src_bytes, dst_bytes;
+    int cc_mode;  // option "cc_mode", snapshotted by the caller: 0 auto, 1 the 4-pixel kernel, 2 wide + nt stores, 3 store-shaped
 };
-void set_color_convert_mode(int mode);  // 0 auto, 1 always the 4-pixel kernel, 2 wide kernel with non-temporal stores
-// src_pixel != dst_pixel.  Returns hipSuccess or the launch error.
-hipError_t launch_color_convert(int src_pixel, int dst_pixel, const ConvertParams &p, hipStream_t s);
+// src_pixel != dst_pixel.  Returns hipSuccess or the launch error; *kernel_name = the kernel layout that was launched.
+hipError_t launch_color_convert(int src_pixel, int dst_pixel, const ConvertParams &p, hipStream_t s, const char **kernel_name);
+
+// ---- work items (r03): an explicit list of (column-strip block, output rows [y0, y1), image) per workgroup ---------
+// Without it a launch is a 3-D grid of equal row chunks.  With it the host orders the work: the list is 8 sub-lists of
+// `items_per_xcd` entries, one per XCD (workgroups are dealt to XCDs round-robin by linear id), each a contiguous piece of
+// the batch in (image, rows, strip) order — neighbouring strips of the same rows run on one XCD at about the same time —
+// whose LAST entries are short row chunks, so that the waves still running when the list runs dry are short ones.
+//   queue == nullptr  one workgroup per item: item of workgroup id L = sub-list L % 8, entry L / 8
+//   queue != nullptr  persistent launch: the grid is only as many workgroups as the chip holds at once; each takes items
+//                     from its XCD's sub-list with an atomic counter (queue[xcd], zeroed before the launch) and steals
+//                     from the other XCDs' sub-lists once its own is exhausted
+struct WorkList {
+    const int4 *items = nullptr;   // {strip block, y0, y1, image}; y0 == y1: padding
+    int items_per_xcd = 0;
+    unsigned *queue = nullptr;     // [8]
+};
 
 // ---- resize: two-pass kernels through an HBM scratch (any geometry) ---------------------------
 struct TwoPassParams {
@@ -81,6 +96,9 @@ struct FusedParams {
     const int32_t *yrow_rec;    // [src_h + 8][2 * nacc]
     const int32_t *yrow_range;  // [dst_h][2]
     int nacc;
+    int xch;  // accumulator kernel, neighbour-exchange form: a lane loads only its own x_step * x_per_lane pixels (uniform-base x table)
+    WorkList work;  // accumulator kernel only: explicit work items / persistent launch
+    int *resident_query;  // host pointer; set: launch nothing, report how many workgroups of this kernel the device holds at once
 };
 // Accumulator kernel: instantiations exist for x tap buckets >= 4 and nacc in {4, 6}.  Windows of 37..128 taps go to the
 // long-window variant, which walks the window in segments of acc_long_segment() pixels (64..96 bytes: measured best —
@@ -89,6 +107,7 @@ struct FusedParams {
 constexpr int acc_long_segment(int bytes_per_pixel) { return bytes_per_pixel <= 3 ? 32 : (bytes_per_pixel <= 6 ? 16 : 8); }
 bool acc_supported(int pixel, int x_taps_bucket, int nacc);
 bool acc_p2_supported(int pixel, int step, int taps, int nacc);  // two outputs per lane: window of the second `step` pixels after the first
+bool acc_xch_supported(int pixel, int per_lane, int step, int taps, int nacc);  // neighbour-exchange form (dword-sized pixels)
 hipError_t launch_resize_acc(int pixel, const FusedParams &p, hipStream_t s, const char **kernel_name);
 // True if a fused instantiation exists for this format / tap counts and its LDS ring fits.
 bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots, int per_lane);
@@ -150,12 +169,17 @@ struct StreamParams {
     int cx0, cx1, x_base;
     int block_waves;  // waves per workgroup (1..4)
     int sync_steps;   // 1: one s_barrier per step keeps a workgroup's waves in lockstep (shared edge lines hit in L1)
+    int xch;          // 1: neighbour-exchange variant (a lane loads only its own x_step * x_per_lane pixels; uniform-base x table)
+    WorkList work;    // resize_sym_kernel only: explicit work items / persistent launch
 };
 bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot);
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty);
-bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty);
+bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int xch = 0);
 hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
+// workgroups of the persistent form the device holds at once for the configuration in p (0: no such instantiation)
+int sym_kernel_resident_blocks(int pixel, const StreamParams &p);
+int acc_kernel_resident_blocks(int pixel, const FusedParams &p);  // 0: unknown / unsupported
 
 // ---- resize: row-staged kernel (kernels_rows.hip): pixels converted once per row into LDS, optional fused colour convert ----
 struct RowsParams {

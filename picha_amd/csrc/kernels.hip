@@ -24,18 +24,27 @@ PICHA_DECL_STREAM(4) PICHA_DECL_STREAM(5) PICHA_DECL_STREAM(6) PICHA_DECL_STREAM
 
 // defined in kernels_sym.hip, one translation unit per pixel format
 #define PICHA_DECL_SYM(N)                                                                \
-    bool sym_supported_pixel##N(int per_lane, int sx, int tx, int sy, int ty);            \
-    hipError_t launch_sym_pixel##N(const StreamParams &p, hipStream_t s, const char **name);
+    bool sym_supported_pixel##N(int per_lane, int sx, int tx, int sy, int ty, int xch);   \
+    hipError_t launch_sym_pixel##N(const StreamParams &p, hipStream_t s, const char **name); \
+    int sym_resident_pixel##N(const StreamParams &p);
 PICHA_DECL_SYM(0) PICHA_DECL_SYM(1) PICHA_DECL_SYM(2) PICHA_DECL_SYM(3)
 PICHA_DECL_SYM(4) PICHA_DECL_SYM(5) PICHA_DECL_SYM(6) PICHA_DECL_SYM(7)
 #undef PICHA_DECL_SYM
-bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty) {
+bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int xch) {
     switch (pixel) {
-#define PICHA_CASE(N) case N: return sym_supported_pixel##N(per_lane, sx, tx, sy, ty);
+#define PICHA_CASE(N) case N: return sym_supported_pixel##N(per_lane, sx, tx, sy, ty, xch);
     PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
 #undef PICHA_CASE
     }
     return false;
+}
+int sym_kernel_resident_blocks(int pixel, const StreamParams &p) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return sym_resident_pixel##N(p);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return 0;
 }
 hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **name) {
     switch (pixel) {
@@ -101,8 +110,8 @@ bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty) {
 // ---------------------------------------------------------------------------------------------
 // Launch interface
 // ---------------------------------------------------------------------------------------------
-void set_color_convert_mode(int mode) { g_cc_mode = mode; }
-hipError_t launch_color_convert(int sp, int dp, const ConvertParams &p, hipStream_t s) {
+hipError_t launch_color_convert(int sp, int dp, const ConvertParams &p, hipStream_t s, const char **name) {
+    if (name) *name = g_kernel_name;  // filled by the launcher that runs
     switch (sp) {
     case 0: return launch_cc_src<0>(dp, p, s);
     case 1: return launch_cc_src<1>(dp, p, s);
@@ -160,6 +169,10 @@ bool fused_x_bytespan(int x_taps_bucket, int pixel) {  // aligned fetch: the hos
 bool acc_p2_supported(int pixel, int step, int taps, int nacc) {
     return pixel >= 0 && pixel <= 7 && (nacc == 4 || nacc == 6) && acc_p2_shape(step, taps);
 }
+bool acc_xch_supported(int pixel, int per_lane, int step, int taps, int nacc) {
+    const int bpp = pixel_channels(pixel) * (pixel_is16(pixel) ? 2 : 1);
+    return pixel >= 0 && pixel <= 7 && bpp % 4 == 0 && (nacc == 4 || nacc == 6) && acc_xch_shape(per_lane, step, taps);
+}
 bool acc_supported(int pixel, int x_taps_bucket, int nacc) {
     if (pixel < 0 || pixel > 7 || (nacc != 4 && nacc != 6)) return false;
     if (x_taps_bucket > 36) {  // resize_acc_long_kernel: multiples of half a segment
@@ -179,6 +192,14 @@ hipError_t launch_resize_acc(int pixel, const FusedParams &p, hipStream_t s, con
 #undef PICHA_CASE
     }
     return hipErrorInvalidValue;
+}
+
+int acc_kernel_resident_blocks(int pixel, const FusedParams &p) {
+    FusedParams q = p;
+    int n = 0;
+    q.resident_query = &n;
+    if (launch_resize_acc(pixel, q, nullptr, nullptr) != hipSuccess) return 0;
+    return n;
 }
 
 bool fused_multi_supported(int pixel, int per_lane, int step, int x_taps) {

@@ -66,26 +66,29 @@ __device__ __forceinline__ void store_lane_outputs(const float (&v)[P][CH], __am
 }
 
 // NBUF row buffers in registers (NBUF - 1 rows in flight per wave): 3 unless a row is more than 12 dwords per lane
-template <int CH, bool S16, int P, int SX, int TX> constexpr int sym_nbuf() { return SpanCfg<CH, S16, P, SX, TX>::NW <= 12 ? 3 : 2; }
+template <int CH, bool S16, int P, int SX, int TX, bool XCH> constexpr int sym_nbuf() {
+    return (XCH ? XchCfg<CH, S16, P, SX, TX>::NOWN + XchCfg<CH, S16, P, SX, TX>::NE : SpanCfg<CH, S16, P, SX, TX>::NW) <= 12 ? 3 : 2;
+}
 
-template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA>
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA, bool XCH = false>
 __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
     using C = SpanCfg<CH, S16, P, SX, TX>;
-    constexpr int NBUF = sym_nbuf<CH, S16, P, SX, TX>();
+    using X = XchCfg<CH, S16, P, SX, TX>;
+    static_assert(!XCH || X::OK, "neighbour exchange: dword pixels, halo within one lane's pixels");
+    constexpr int NRAW = XCH ? X::NRAW : C::NW;  // registers per row buffer
+    constexpr int NBUF = sym_nbuf<CH, S16, P, SX, TX, XCH>();
     constexpr int NPEND = (TY - 1) / SY + 1;
     constexpr int ICLOSE = (TY - 1) / SY, PHCLOSE = (TY - 1) % SY;
     constexpr int YW = (NPEND * SY + 1 + 3) / 4 * 4;  // dwords per step record: NPEND*SY weights, flags in the last dword
     constexpr int TXH = (TX + 1) / 2, TYH = (TY + 1) / 2;
 
-    unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-    if (p.xcd_remap) xcd_contiguous_block(bx, by, bz);
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    auto run_item = [&](int bx, int y0, int y1, int img) __attribute__((always_inline)) {
     const int grp0 = (bx * (blockDim.x >> 6) + wave) * kWave;  // 1..4 waves per workgroup (host's choice)
-    if (grp0 * P >= p.dst_w) return;  // wave-uniform; the kernel has no barriers
+    if (grp0 * P >= p.dst_w) return;  // wave-uniform; the march has no barriers
     const int x0 = (grp0 + lane) * P;
 
-    const int img = bz;
     const uint8_t *sbase = p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch;
     uint8_t *dbase = p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch;
     const int sadj = C::BROT ? int(reinterpret_cast<uintptr_t>(sbase) & 3u) : 0;
@@ -93,8 +96,6 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
         const_cast<uint8_t *>(sbase) - sadj, 0, C::BROT ? ((p.src_bytes + sadj + 3u) & ~3u) : p.src_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
 
-    const int y0 = by * p.rows_per_chunk;
-    const int y1 = min(p.dst_h, y0 + p.rows_per_chunk);
     if (y0 >= y1) return;
     const int m_end = y1 - 1 + ICLOSE;  // last step that completes an output row of this chunk
     const_i32_ptr ystep = (const_i32_ptr)(p.y_step_weight);
@@ -124,17 +125,29 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
             lane_off = p.x_left[grp] * C::BPP + sadj;
             neg_lane = __any(lane_off < 0);
         }
+        // XCH: the lane's own pixels start at SX * x0 (the table is uniform-base: every window starts HL pixels before them)
+        if constexpr (XCH) { lane_off = SX * x0 * C::BPP; neg_lane = false; }
+        const bool edge_lane = lane == 0 || lane == kWave - 1;
+        const int32_t edge_off = lane == 0 ? -X::M * C::BPP : X::OWN * C::BPP;
         float wyc[TYH];
 #pragma unroll
         for (int id = 0; id < TYH; ++id) asm volatile("v_mov_b32 %0, %1" : "=v"(wyc[id]) : "s"(p.y_canon[id]));
 
         float acc[NPEND][P][CH];  // static roles: at step index K of the unrolled group, output m - i lives in slot (i - K) mod NPEND
-        uint32_t raw[NB][C::NW];
+        uint32_t raw[NB][NRAW];
+        if constexpr (XCH) {  // halo registers of the lanes that never load them: defined once, kept by the masked loads
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int k = X::NOWN; k < NRAW; ++k) raw[b][k] = 0u;
+        }
 
-        auto load_row = [&](uint32_t (&t)[C::NW], int row) __attribute__((always_inline)) {
+        auto load_row = [&](uint32_t (&t)[NRAW], int row) __attribute__((always_inline)) {
             const int rr = (row >= p.src_h) ? p.src_h : row;  // rows outside the image read 0 (outside the descriptor)
             const int32_t off = rr * p.src_stride + lane_off;
-            if constexpr (XC) {
+            if constexpr (XCH) {
+                xch_load_row<X>(src_rs, off, edge_lane, edge_off, t);
+            } else if constexpr (XC) {
                 load_span<C, false>(src_rs, off, t);
             } else {
                 // a lane whose span starts before the image (left edge): in row 0 a wrapped offset would void the whole
@@ -162,13 +175,14 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
                 load_row(raw[bn], row + NB - 1);
                 // ---- horizontal pass (src/resize.cc:110-117) ----
                 float h[P][CH];
-                uint32_t win[C::BROT ? C::NWIN : 1];
+                uint32_t win[XCH ? X::NWIN : (C::BROT ? C::NWIN : 1)];
+                if constexpr (XCH) xch_window<X>(raw[bi], win);
                 if constexpr (C::BROT)
                     rotate_span<C>(raw[bi], uint32_t(((row >= p.src_h) ? p.src_h : row) * p.src_stride + lane_off) & 3u, win);
 #pragma unroll
                 for (int q = 0; q < C::SPAN; ++q) {
                     float u[CH];
-                    if constexpr (C::BROT) unpack_span_px<C, CH, S16, FMA>(win, q, u);
+                    if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, q, u);
                     else unpack_span_px<C, CH, S16, FMA>(raw[bi], q, u);
 #pragma unroll
                     for (int o = 0; o < P; ++o) {
@@ -239,18 +253,36 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
     // allocation (the maximum over both versions) is set by the interior version
     if (interior) march(std::true_type{}, IC<NBUF>{});
     else march(std::false_type{}, IC<(NBUF > 2 ? NBUF - 1 : 2)>{});
+    };  // run_item
+    run_work_items(p.work, [&](int &ibx, int &y0, int &y1, int &img) __attribute__((always_inline)) {
+        unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+        if (p.xcd_remap) xcd_contiguous_block(bx, by, bz);
+        ibx = int(bx); y0 = int(by) * p.rows_per_chunk; y1 = min(p.dst_h, y0 + p.rows_per_chunk); img = int(bz);
+    }, run_item);
 }
 
-template <int CH, bool S16, int P, int SX, int TX, int SY, int TY>
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool XCH = false>
 hipError_t launch_sym_t(const StreamParams &p, hipStream_t s, const char **name) {
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 2;
     dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
-    if (p.fma) resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true><<<grid, 64 * bw, 0, s>>>(p);
-    else resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false><<<grid, 64 * bw, 0, s>>>(p);
-    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_sym<ch%d,%s,P%d,SX%d,TX%d,SY%d,TY%d,%s,bw%d>", CH, S16 ? "u16" : "u8", P, SX, TX, SY,
-             TY, p.fma ? "fma" : "exact", bw);
+    if (p.work.items) grid = dim3(p.work.queue ? (unsigned)p.n_chunks : 8u * (unsigned)p.work.items_per_xcd, 1, 1);  // persistent: n_chunks = resident workgroups
+    if (p.fma) resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true, XCH><<<grid, 64 * bw, 0, s>>>(p);
+    else resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false, XCH><<<grid, 64 * bw, 0, s>>>(p);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_sym<ch%d,%s,P%d,SX%d,TX%d,SY%d,TY%d,%s,bw%d%s%s>", CH, S16 ? "u16" : "u8", P, SX, TX, SY,
+             TY, p.fma ? "fma" : "exact", bw, XCH ? ",xch" : "", p.work.queue ? ",persistent" : p.work.items ? ",items" : "");
     if (name) *name = g_kernel_name;
     return hipGetLastError();
+}
+
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool XCH = false>
+int sym_resident_t(const StreamParams &p) {
+    const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 2;
+    int per_cu = 0, dev = 0, cus = 0;
+    const void *k = p.fma ? reinterpret_cast<const void *>(resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true, XCH>)
+                          : reinterpret_cast<const void *>(resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false, XCH>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * bw, 0) != hipSuccess) return 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+    return per_cu * cus;
 }
 
 // Instantiations per pixel format: X(P, SX, TX, SY, TY) — the (format, scale, tap count, outputs per lane) combinations that
@@ -271,6 +303,16 @@ hipError_t launch_sym_t(const StreamParams &p, hipStream_t s, const char **name)
 #define PICHA_SYM_LIST_6(X) /* r16g16b16 */ X(2, 2, 3, 2, 3) X(2, 2, 5, 2, 5) X(2, 2, 7, 2, 7) X(2, 3, 12, 3, 12)
 #define PICHA_SYM_LIST_7(X) /* r16g16b16a16 */ X(2, 2, 3, 2, 3) X(2, 2, 5, 2, 5) X(2, 2, 7, 2, 7) X(2, 3, 12, 3, 12)
 
+// Neighbour-exchange instantiations: Y(P, SX, TX, SY, TY), dword-sized pixels only.
+#define PICHA_SYMX_LIST_0(Y)
+#define PICHA_SYMX_LIST_1(Y) /* rgba */ Y(2, 2, 5, 2, 5) Y(3, 2, 5, 2, 5) Y(4, 2, 5, 2, 5) Y(2, 2, 7, 2, 7) Y(3, 2, 7, 2, 7) Y(2, 3, 8, 3, 8)
+#define PICHA_SYMX_LIST_2(Y)
+#define PICHA_SYMX_LIST_3(Y)
+#define PICHA_SYMX_LIST_4(Y)
+#define PICHA_SYMX_LIST_5(Y) /* r16g16 */ Y(2, 2, 5, 2, 5) Y(4, 2, 5, 2, 5) Y(3, 2, 7, 2, 7)
+#define PICHA_SYMX_LIST_6(Y)
+#define PICHA_SYMX_LIST_7(Y) /* r16g16b16a16 */ Y(2, 2, 5, 2, 5) Y(2, 2, 7, 2, 7)
+
 }  // namespace
 
 #ifndef PICHA_SYM_PIXEL
@@ -279,15 +321,40 @@ hipError_t launch_sym_t(const StreamParams &p, hipStream_t s, const char **name)
 #define PICHA_CAT2(a, b) a##b
 #define PICHA_CAT(a, b) PICHA_CAT2(a, b)
 #define PICHA_SYM_LIST PICHA_CAT(PICHA_SYM_LIST_, PICHA_SYM_PIXEL)
+#define PICHA_SYMX_LIST PICHA_CAT(PICHA_SYMX_LIST_, PICHA_SYM_PIXEL)
 
-bool PICHA_CAT(sym_supported_pixel, PICHA_SYM_PIXEL)(int per_lane, int sx, int tx, int sy, int ty) {
-#define X(P, SX, TX, SY, TY) if (per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY) return true;
+bool PICHA_CAT(sym_supported_pixel, PICHA_SYM_PIXEL)(int per_lane, int sx, int tx, int sy, int ty, int xch) {
+#define X(P, SX, TX, SY, TY) if (!xch && per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY) return true;
     PICHA_SYM_LIST(X)
 #undef X
+#define Y(P, SX, TX, SY, TY) if (xch && per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY) return true;
+    PICHA_SYMX_LIST(Y)
+#undef Y
     return false;
 }
 
+int PICHA_CAT(sym_resident_pixel, PICHA_SYM_PIXEL)(const StreamParams &p) {
+#define Y(P, SX, TX, SY, TY)                                                                                          \
+    if (p.xch && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY)           \
+        return sym_resident_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY, true>(p);
+    PICHA_SYMX_LIST(Y)
+#undef Y
+    if (p.xch) return 0;
+#define X(P, SX, TX, SY, TY)                                                                                          \
+    if (p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY)                     \
+        return sym_resident_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY>(p);
+    PICHA_SYM_LIST(X)
+#undef X
+    return 0;
+}
+
 hipError_t PICHA_CAT(launch_sym_pixel, PICHA_SYM_PIXEL)(const StreamParams &p, hipStream_t s, const char **name) {
+#define Y(P, SX, TX, SY, TY)                                                                                          \
+    if (p.xch && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY)           \
+        return launch_sym_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY, true>(p, s, name);
+    PICHA_SYMX_LIST(Y)
+#undef Y
+    if (p.xch) return hipErrorInvalidValue;
 #define X(P, SX, TX, SY, TY)                                                                                          \
     if (p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY)                     \
         return launch_sym_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY>(p, s, name);

@@ -13,21 +13,38 @@ function sizeOf(pixel) {
 	return Object.prototype.hasOwnProperty.call(BYTES_PER_PIXEL, pixel) ? BYTES_PER_PIXEL[pixel] : 0;
 }
 
+// Geometry of an image request: falsy fields take the API defaults (lib/image.js:3-9 of the reference: width / height 0,
+// pixel 'rgba', rows padded to 4 bytes), then the four checks in the reference's order with its messages (lib/image.js:10-20).
+function resolveLayout(req) {
+	const layout = {
+		width: req.width ? req.width : 0,
+		height: req.height ? req.height : 0,
+		pixel: req.pixel ? req.pixel : 'rgba',
+	};
+	const bpp = sizeOf(layout.pixel);
+	const payload = layout.width * bpp;          // bytes of a row that carry pixels
+	layout.stride = req.stride ? req.stride : ((payload + 3) & ~3);
+	if (bpp === 0) throw new Error("invalid pixel format " + layout.pixel);
+	if (layout.stride < payload) throw new Error("stride too short");
+	if (layout.width < 0 || layout.height < 0) throw new Error("invalid dimensions");
+	layout.bytes = layout.stride * layout.height;                         // a freshly allocated image
+	layout.minBytes = layout.stride * (layout.height - 1) + payload;      // the last row may stop at its payload
+	return layout;
+}
+
 class Image {
 	constructor(opt) {
-		opt = opt || {};
-		this.data = opt.data;
-		this.width = opt.width || 0;
-		this.height = opt.height || 0;
-		this.pixel = opt.pixel || 'rgba';
-		const psize = sizeOf(this.pixel);
-		this.stride = opt.stride || ((this.width * psize + 3) & ~3);
-		if (psize === 0) throw new Error("invalid pixel format " + this.pixel);
-		if (this.stride < this.width * psize) throw new Error("stride too short");
-		if (this.width < 0 || this.height < 0) throw new Error("invalid dimensions");
-		if (this.stride * this.height !== 0 && !this.data) this.data = Buffer.alloc(this.stride * this.height);
-		if (this.data && this.data.length < this.stride * (this.height - 1) + this.width * psize)
-			throw new Error("image data too small");
+		const req = opt || {};
+		this.data = req.data;                  // first, so the property order matches the reference's objects
+		const layout = resolveLayout(req);
+		this.width = layout.width;
+		this.height = layout.height;
+		this.pixel = layout.pixel;
+		this.stride = layout.stride;
+		let store = req.data;
+		if (!store && layout.bytes !== 0) store = Buffer.alloc(layout.bytes);   // zero-filled, like the reference
+		if (store && store.length < layout.minBytes) throw new Error("image data too small");
+		this.data = store;
 	}
 
 	static pixelSize(pixel) { return sizeOf(pixel); }
@@ -64,20 +81,24 @@ class Image {
 		return sum / (this.height * rw);
 	}
 
-	// a window onto the same memory (same stride)
+	// byte offset of pixel (x, y) inside this.data
+	offsetOf(x, y) { return y * this.stride + x * this.pixelSize(); }
+
+	// a w x h window with its top-left corner at (x, y): shares this image's memory and stride; the view's buffer ends
+	// with the payload of its last row (lib/image.js:76-87)
 	subView(x, y, w, h) {
-		const p = this.pixelSize();
-		const off = y * this.stride + x * p;
-		const len = (h - 1) * this.stride + w * p;
-		return new Image({ width: w, height: h, pixel: this.pixel, stride: this.stride, data: this.data.slice(off, off + len) });
+		const first = this.offsetOf(x, y);
+		const last = this.offsetOf(x + w, y + h - 1);   // one past the last payload byte of the window
+		return new Image({ data: this.data.slice(first, last), stride: this.stride, pixel: this.pixel, width: w, height: h });
 	}
 
+	// copies the common top-left rectangle into `target`, payload bytes only (lib/image.js:89-96)
 	copy(target) {
 		if (target.pixel != this.pixel) throw new Error("can't copy pixels between different pixel types");
-		const rw = this.pixelSize() * Math.min(this.width, target.width);
-		const h = Math.min(this.height, target.height);
-		for (let y = 0; y < h; ++y)
-			this.data.copy(target.data, y * target.stride, y * this.stride, y * this.stride + rw);
+		const rows = Math.min(this.height, target.height);
+		const bytes = Math.min(this.width, target.width) * this.pixelSize();
+		for (let from = 0, to = 0, y = 0; y < rows; ++y, from += this.stride, to += target.stride)
+			this.data.copy(target.data, to, from, from + bytes);
 	}
 }
 

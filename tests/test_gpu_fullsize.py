@@ -23,7 +23,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "sym", "block_waves"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "sym", "block_waves", "xch"):
         set_opt(k, 0)
 
 
@@ -42,13 +42,18 @@ def test_cfg2_full_batch_kernel_families_agree_and_match_oracle():
     n = 256
     src = DeviceBatch(n, 3840, 2160, "rgba").fill_random(20250226)
     sums = {}
-    for path, per_lane in ((2, 2), (2, 1), (3, 2), (3, 1)):  # streaming and LDS-ring kernels, two lane layouts
+    # (0, 0) = the planner's own choice: the launch bench.py times (all 256 images of it are in the digest); then the
+    # streaming and LDS-ring kernels in two lane layouts each, and both forms of the symmetric-table kernel (with and
+    # without the neighbour exchange)
+    for path, per_lane, xch in ((0, 0, 0), (2, 2, 0), (2, 1, 0), (3, 2, 0), (3, 1, 0), (0, 3, 1), (0, 3, 2)):
         set_opt("path", path)
         set_opt("per_lane", per_lane)
+        set_opt("xch", xch)
         out = resize_batch(src, 1920, 1080)
         torch.cuda.synchronize()
-        sums[N.lib().picha_hip_last_kernel().decode()] = digest(out)
-    assert len(sums) == 4 and len(set(sums.values())) == 1, sums
+        sums["%s (path %d, per_lane %d, xch %d)" % (N.lib().picha_hip_last_kernel().decode(), path, per_lane, xch)] = digest(out)
+    assert len({k.split(" (")[0] for k in sums}) >= 6 and len(set(sums.values())) == 1, sums
+    set_opt("xch", 0)
     # oracle spot check: first and last image of the batch (bit-exact)
     for i in (0, n - 1):
         exp = oracle_resize(src.image_host(i), 1920, 1080, "cubic", 0.70)
