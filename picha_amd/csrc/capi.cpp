@@ -88,8 +88,9 @@ long g_opt_acc_p2 = 0;      // accumulator kernel with two outputs per lane: 0 a
 long g_opt_sym_sync = 0;    // 1: a barrier per step keeps the waves of a workgroup in lockstep
 long g_opt_work = 0;        // sym / accumulator kernels, work items: 0 auto, 1 explicit item list (one workgroup per item, short chunks last),
                             // 2 persistent launch (resident workgroups pull items from per-XCD atomic queues), 3 plain 3-D grid
-long g_opt_work_tail = 120; // per mille of every XCD's sub-list that is cut into short row chunks
+long g_opt_work_tail = 200; // per mille of every XCD's sub-list that is cut into short row chunks
 long g_opt_work_tail_div = 4;  // ... short chunk = long chunk / this
+long g_opt_up = 0;          // integer upscales on the accumulator kernel (several outputs per lane, register accumulators): 0 auto (16-bit formats), 1 always, 2 never
 long g_opt_xch = 0;         // symmetric-table kernel, neighbour exchange (a lane loads only its own pixels): 0 auto, 1 wherever instantiated, 2 never
 
 // ---- per-device state ---------------------------------------------------------------------------
@@ -627,14 +628,26 @@ bool sym_xch_preferred(int pixel, int step, int taps, int per_lane, int fma) {
 }
 
 // default work mode of a launch with `n` images, `col_waves` waves per output row and `chunks` row chunks (0 = plain grid)
-int work_default(int n, long long col_waves, int chunks) {
-    (void)n; (void)col_waves; (void)chunks;
-    return 0;
+// Measured r03 (profiles/r03_ab_work_items.txt): cfg2 on the symmetric-table kernel -2.3 .. -3.2 % with the explicit list (the
+// tail of short chunks), the persistent form +6 % there (an atomic and two barriers per item, no launch-time backfill to save);
+// cfg5 on the neighbour-exchange accumulator kernel, whose plain grid is only 2.7 rounds of resident workgroups: list -1.3 %,
+// persistent -2 %.  Small launches keep the plain grid: the list only pays once a launch is several rounds long.
+// Everything else on the accumulator kernel keeps the plain grid: on short launches (64 x 960x540 upscales, 0.1-0.4 ms) the list is
+// 0-5 % and the persistent form 10-100 % slower (profiles/r03_survey_upscale.txt).
+int work_default(int n, long long col_waves, int chunks, bool acc_kernel, bool acc_xch) {
+    const long long waves = (long long)n * col_waves * chunks;
+    if (waves < 6144) return 0;
+    if (acc_kernel) return acc_xch ? 2 : 0;
+    return 1;
 }
 
+// where the neighbour-exchange form of the accumulator kernel is the default (measured r03, profiles/r03_ab_xch.txt): cfg5's
+// shape — r16g16b16a16 at 4x with 15 taps, every source byte requested by four lanes in the plain form: -8 % (reference
+// arithmetic), -11 % (fma).  rgba at 3x / 4x (8 and 11 taps) and the symmetric-table kernel at 2x lose 1-13 % with it: the
+// L1 is not their limit and the DPP moves and the edge lanes' extra load cost more than the narrower loads save.
 bool acc_xch_preferred(int pixel, int step, int taps, int per_lane, int fma) {
-    (void)pixel; (void)step; (void)taps; (void)per_lane; (void)fma;
-    return false;
+    (void)fma;
+    return pixel == PICHA_R16G16B16A16 && step == 4 && taps == 15 && per_lane == 2;
 }
 
 // Outputs per lane for which resize_sym_kernel beats the general streaming / accumulator kernels by >= 2 % (0: it does not):
@@ -928,9 +941,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
     long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_bw, opt_sym_sync, opt_acc_p2, opt_xch;
-    long opt_work, opt_work_tail, opt_work_tail_div;
+    long opt_work, opt_work_tail, opt_work_tail_div, opt_up;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
+        opt_up = g_opt_up;
         opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
         opt_xch = g_opt_xch;
         opt_sym = g_opt_sym; opt_bw = g_opt_block_waves; opt_sym_sync = g_opt_sym_sync; opt_acc_p2 = g_opt_acc_p2;
@@ -956,9 +970,44 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     }
     int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps, pixel);  // includes alignment room where needed
     const DeviceAxis::XTable *xt = nullptr;
+    const DeviceAxis::YRows *yr = nullptr;   // accumulator kernel: per-source-row records ...
+    const DeviceAxis::XTable *xa = nullptr;  // ... and its x table
+    int nacc = 0, acc_per_lane = 1, acc_x_step = 1;
+    bool acc_xch = false;
+    int ataps = fused_x_bucket(ax->host.taps, pixel, true);  // the accumulator kernel's own (finer) x bucket
+    // integer upscales (r03): the accumulator kernel with several outputs per lane sharing one window and as many register
+    // accumulators as output rows hold a source row (kernels_impl.inc, PICHA_ACC_UP_SHAPES) instead of the span kernel's LDS
+    // ring.  Ring-aliasing tables (box / lanczos at exact factors) are not representable and stay on the span kernel.
+    // Measured r03 (64 x 960x540 -> 1080p, profiles/r03_survey_upscale.txt): the 16-bit formats gain 1.4-3.9x over the one-output
+    // accumulator kernel that served them (r16 0.11 -> 0.43 of the roof, r16g16 0.21 -> 0.48, r16g16b16a16 0.37 -> 0.50); the 8-bit
+    // formats stay 15-25 % behind their span instantiations (the per-row records and completion tests of this kernel outweigh
+    // the LDS ring of that one when a lane has 4-16 values per row), so "up" = 0 takes it for 16-bit samples only, 1 always.
+    if (fused_ok && (opt_up == 1 || (opt_up == 0 && is16)) && opt_path != 1 && opt_path != 3 && opt_acc != 2 && d0.width >= 2 * s0.width &&
+        (opt_per_lane == 0 || opt_per_lane == 2 || opt_per_lane == 4)) {
+        const bool sub = kBytes[pixel] % 4 != 0;
+        const int pl = sub ? 4 : 2;
+        bool dword_rows = true;
+        for (int i = 0; i < n && sub; ++i)
+            if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % 4) dword_rows = false;
+        const int kt = ax->host.taps + (pl == 4 ? 2 : 1);
+        if (dword_rows && (opt_per_lane == 0 || opt_per_lane == pl)) {
+            for (int na : {6, 8, 12}) {
+                if (!acc_up_supported(pixel, pl, kt, na)) continue;
+                const DeviceAxis::YRows *cand = nullptr;
+                rc = get_yrows(ctx, ay, na, &cand);
+                if (rc) return rc;
+                if (!cand->ok) continue;
+                const DeviceAxis::XTable *cx = nullptr;
+                rc = get_xtable(ctx, ax, pl, 0, kt, xw_mode, is16, &cx);
+                if (rc) return rc;
+                if (cx->ok) { yr = cand; nacc = na; xa = cx; acc_per_lane = pl; acc_x_step = 0; ataps = kt; }
+                break;
+            }
+        }
+    }
     // upscales by >= 2 of the 8-bit sub-dword formats (rgb, grey, greya): four outputs per lane sharing one window, whole-dword
     // stores (the one-output-per-lane span kernel is bound by its 1-3 byte stores: 0.15-0.26 of the roof, r01 survey)
-    if (fused_ok && (opt_per_lane == 0 || opt_per_lane == 4) && opt_path != 4 && opt_path != 1 && kBytes[pixel] % 4 != 0 && pixel < PICHA_R16 &&
+    if (fused_ok && !yr && (opt_per_lane == 0 || opt_per_lane == 4) && opt_path != 4 && opt_path != 1 && kBytes[pixel] % 4 != 0 && pixel < PICHA_R16 &&
         d0.width >= 2 * s0.width) {
         bool dword_rows = true;
         for (int i = 0; i < n; ++i)
@@ -971,7 +1020,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             if (cx->ok) { xt = cx; per_lane = 4; step = 0; ktaps = kt; }
         }
     }
-    if (fused_ok && !xt && opt_per_lane != 1 && opt_path != 4) {
+    if (fused_ok && !xt && !yr && opt_per_lane != 1 && opt_path != 4) {
         // integer decimation / interpolation step of the tap windows
         const int st = std::max(1, (int)std::lround((double)s0.width / d0.width));
         static const int cand[] = {2, 4};
@@ -987,7 +1036,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         }
     }
     // ---- streaming kernel (uniform tables in x and y, no LDS): preferred when available
-    if (fused_ok && opt_path != 1 && opt_path != 3 && opt_path != 4) {
+    if (fused_ok && !yr && opt_path != 1 && opt_path != 3 && opt_path != 4) {
         const int sx = std::max(1, (int)std::lround((double)s0.width / d0.width));
         const int sy = std::max(1, (int)std::lround((double)s0.height / d0.height));
         // lane layouts, measured on cfg2 with the XCD-contiguous workgroup order (profiles/r01_ab_xcd_remap.txt): two
@@ -1059,7 +1108,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
             p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
             // work items (sym kernel): explicit list with short chunks last, optionally pulled by persistent workgroups
-            const int work_mode = !sym || p.sync_steps ? 0 : opt_work == 3 ? 0 : opt_work > 0 ? (int)opt_work : work_default(n, col_waves, p.n_chunks);
+            const int work_mode = !sym || p.sync_steps ? 0 : opt_work == 3 ? 0 : opt_work > 0 ? (int)opt_work : work_default(n, col_waves, p.n_chunks, false, false);
             if (work_mode) {
                 const int nsb = (int)((cx->groups + 64 * bw - 1) / (64 * bw));
                 const DeviceCtx::ItemList *il = nullptr;
@@ -1178,18 +1227,13 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     // ---- accumulator kernel (no ring): any downscale whose span-kernel ring would be large.  The ring costs
     // (window rows) x 64 lanes x 4..16 B of LDS per wave and caps the occupancy (a 7.5x thumbnail: 22 KB per wave,
     // 7 waves per CU); the accumulator kernel keeps nacc x channels registers instead.
-    const DeviceAxis::YRows *yr = nullptr;
-    const DeviceAxis::XTable *xa = nullptr;
-    int nacc = 0, acc_per_lane = 1, acc_x_step = 1;
-    bool acc_xch = false;
     constexpr int kAccMinRing = 1;  // measured faster than the span kernel for every ring size it was tried on (profiles/r01_survey_acc_vs_span.txt)
-    int ataps = fused_x_bucket(ax->host.taps, pixel, true);  // the accumulator kernel's own (finer) x bucket
-    const bool acc_long = ataps == 0 && ax->host.taps > 36 && ax->host.taps <= 128;
+    const bool acc_long = !yr && ataps == 0 && ax->host.taps > 36 && ax->host.taps <= 128;
     if (acc_long) {  // long windows: LDS-resident weights, tap count padded to half a load segment
         const int half = acc_long_segment(kBytes[pixel]) / 2;
         ataps = (ax->host.taps + half - 1) / half * half;
     }
-    if (fused_ok && per_lane == 1 && opt_path != 1 && opt_path != 3 && opt_acc != 2 && ataps > 0 &&
+    if (fused_ok && !yr && per_lane == 1 && opt_path != 1 && opt_path != 3 && opt_acc != 2 && ataps > 0 &&
         (opt_acc == 1 || opt_path == 4 || ring >= kAccMinRing)) {
         for (int na : {4, 6}) {
             if (!acc_supported(pixel, ataps, na)) break;
@@ -1294,7 +1338,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
         p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
         // work items (accumulator kernel, windows up to 36 taps)
-        const int work_mode = !use_acc || ktaps > 36 ? 0 : opt_work == 3 ? 0 : opt_work > 0 ? (int)opt_work : work_default(n, col_waves, p.n_chunks);
+        const int work_mode = !use_acc || ktaps > 36 ? 0 : opt_work == 3 ? 0 : opt_work > 0 ? (int)opt_work : work_default(n, col_waves, p.n_chunks, true, acc_xch);
         if (work_mode) {
             const int nsb = (xt->groups + 255) / 256;
             const DeviceCtx::ItemList *il = nullptr;
@@ -1722,6 +1766,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "block_waves") == 0) { g_opt_block_waves = value; return PICHA_OK; }
     if (strcmp(key, "sym_sync") == 0) { g_opt_sym_sync = value; return PICHA_OK; }
     if (strcmp(key, "xch") == 0) { g_opt_xch = value; return PICHA_OK; }
+    if (strcmp(key, "up") == 0) { g_opt_up = value; return PICHA_OK; }
     if (strcmp(key, "work") == 0) { g_opt_work = value; return PICHA_OK; }
     if (strcmp(key, "work_tail") == 0) { g_opt_work_tail = value; return PICHA_OK; }
     if (strcmp(key, "work_tail_div") == 0) { g_opt_work_tail_div = value; return PICHA_OK; }
@@ -1749,6 +1794,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "block_waves") == 0) return g_opt_block_waves;
     if (strcmp(key, "sym_sync") == 0) return g_opt_sym_sync;
     if (strcmp(key, "xch") == 0) return g_opt_xch;
+    if (strcmp(key, "up") == 0) return g_opt_up;
     if (strcmp(key, "work") == 0) return g_opt_work;
     if (strcmp(key, "work_tail") == 0) return g_opt_work_tail;
     if (strcmp(key, "work_tail_div") == 0) return g_opt_work_tail_div;

@@ -108,6 +108,7 @@ constexpr int acc_long_segment(int bytes_per_pixel) { return bytes_per_pixel <= 
 bool acc_supported(int pixel, int x_taps_bucket, int nacc);
 bool acc_p2_supported(int pixel, int step, int taps, int nacc);  // two outputs per lane: window of the second `step` pixels after the first
 bool acc_xch_supported(int pixel, int per_lane, int step, int taps, int nacc);  // neighbour-exchange form (dword-sized pixels)
+bool acc_up_supported(int pixel, int per_lane, int taps, int nacc);  // integer upscales: per_lane outputs share one window of `taps` pixels (step 0)
 hipError_t launch_resize_acc(int pixel, const FusedParams &p, hipStream_t s, const char **kernel_name);
 // True if a fused instantiation exists for this format / tap counts and its LDS ring fits.
 bool fused_supported(int pixel, int x_taps, int y_taps, int ring_slots, int per_lane);

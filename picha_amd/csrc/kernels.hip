@@ -169,6 +169,19 @@ bool fused_x_bytespan(int x_taps_bucket, int pixel) {  // aligned fetch: the hos
 bool acc_p2_supported(int pixel, int step, int taps, int nacc) {
     return pixel >= 0 && pixel <= 7 && (nacc == 4 || nacc == 6) && acc_p2_shape(step, taps);
 }
+bool acc_up_supported(int pixel, int per_lane, int taps, int nacc) {
+    switch (pixel) {
+    case 0: return acc_up_shape_ok<3, false>(per_lane, taps, nacc);
+    case 1: return acc_up_shape_ok<4, false>(per_lane, taps, nacc);
+    case 2: return acc_up_shape_ok<1, false>(per_lane, taps, nacc);
+    case 3: return acc_up_shape_ok<2, false>(per_lane, taps, nacc);
+    case 4: return acc_up_shape_ok<1, true>(per_lane, taps, nacc);
+    case 5: return acc_up_shape_ok<2, true>(per_lane, taps, nacc);
+    case 6: return acc_up_shape_ok<3, true>(per_lane, taps, nacc);
+    case 7: return acc_up_shape_ok<4, true>(per_lane, taps, nacc);
+    }
+    return false;
+}
 bool acc_xch_supported(int pixel, int per_lane, int step, int taps, int nacc) {
     const int bpp = pixel_channels(pixel) * (pixel_is16(pixel) ? 2 : 1);
     return pixel >= 0 && pixel <= 7 && bpp % 4 == 0 && (nacc == 4 || nacc == 6) && acc_xch_shape(per_lane, step, taps);

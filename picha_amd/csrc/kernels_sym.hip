@@ -25,46 +25,6 @@ namespace {
 template <int N> using IC = std::integral_constant<int, N>;
 constexpr int ce_min(int a, int b) { return a < b ? a : b; }
 
-// pack + store the P pixels of one lane (whole dwords wherever the layout allows it)
-template <typename C, int CH, bool S16, int P, bool FMA>
-__device__ __forceinline__ void store_lane_outputs(const float (&v)[P][CH], __amdgpu_buffer_rsrc_t dst_rs, uint32_t doff, int x0, int dst_w) {
-    if (x0 + P <= dst_w) {
-        if constexpr (C::WORDS) {
-            constexpr int DPP = C::BPP / 4;
-            uint32_t dw[P * DPP];
-#pragma unroll
-            for (int q = 0; q < P; ++q) {
-                uint32_t t[2];
-                pack_px_words<CH, S16, FMA>(v[q], t);
-                dw[q * DPP] = t[0];
-                if constexpr (DPP == 2) dw[q * DPP + 1] = t[1];
-            }
-            store_dwords<P * DPP, kStoreNT>(dst_rs, doff, dw);
-            return;
-        } else if constexpr ((P * C::BPP) % 4 == 0) {
-            // sub-dword pixels: the lane's P pixels are whole dwords at a 4-byte aligned address (host-checked)
-            constexpr int NDW = P * C::BPP / 4, SPD = S16 ? 2 : 4;
-            float flat[P * CH];
-#pragma unroll
-            for (int q = 0; q < P; ++q)
-#pragma unroll
-                for (int c = 0; c < CH; ++c) flat[q * CH + c] = v[q][c];
-            uint32_t dw[NDW];
-#pragma unroll
-            for (int j = 0; j < NDW; ++j) { uint32_t t2[2]; pack_px_words<SPD, S16, FMA>(&flat[SPD * j], t2); dw[j] = t2[0]; }
-            store_dwords<NDW, kStoreNT>(dst_rs, doff, dw);
-            return;
-        }
-    }
-#pragma unroll
-    for (int q = 0; q < P; ++q)
-        if (x0 + q < dst_w) {
-            uint32_t pw[2];
-            pack_px_words<CH, S16, FMA>(v[q], pw);
-            store_px_words<CH, S16, kStoreNT>(dst_rs, doff + q * C::BPP, pw);
-        }
-}
-
 // NBUF row buffers in registers (NBUF - 1 rows in flight per wave): 3 unless a row is more than 12 dwords per lane
 template <int CH, bool S16, int P, int SX, int TX, bool XCH> constexpr int sym_nbuf() {
     return (XCH ? XchCfg<CH, S16, P, SX, TX>::NOWN + XchCfg<CH, S16, P, SX, TX>::NE : SpanCfg<CH, S16, P, SX, TX>::NW) <= 12 ? 3 : 2;
@@ -89,8 +49,8 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
     if (grp0 * P >= p.dst_w) return;  // wave-uniform; the march has no barriers
     const int x0 = (grp0 + lane) * P;
 
-    const uint8_t *sbase = p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch;
-    uint8_t *dbase = p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch;
+    const uint8_t *sbase = uniform_ptr(p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch);
+    uint8_t *dbase = uniform_ptr(p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch);
     const int sadj = C::BROT ? int(reinterpret_cast<uintptr_t>(sbase) & 3u) : 0;
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<uint8_t *>(sbase) - sadj, 0, C::BROT ? ((p.src_bytes + sadj + 3u) & ~3u) : p.src_bytes, 0x00020000);

@@ -16,7 +16,8 @@ import picha_amd
 from picha_amd import _native as N
 from picha_amd.device import DeviceBatch, ResizePlan
 
-KNOBS = ('numerics', 'per_lane', 'path', 'row_chunks', 'stream_rot', 'dpp', 'xcd_remap', 'acc', 'sym', 'block_waves', 'sym_sync', 'rows', 'xch', 'acc_p2', 'work')
+KNOBS = ('numerics', 'per_lane', 'path', 'row_chunks', 'stream_rot', 'dpp', 'xcd_remap', 'acc', 'sym', 'block_waves', 'sym_sync', 'rows', 'xch', 'acc_p2', 'work', 'work_tail', 'work_tail_div', 'up')
+DEFAULTS = {'work_tail': 200, 'work_tail_div': 4}
 
 
 def opt(k, v):
@@ -46,7 +47,7 @@ def main():
     for rnd in range(rounds):
         for vi, v in enumerate(variants):
             for k in KNOBS:
-                opt(k, 0)
+                opt(k, DEFAULTS.get(k, 0))
             for k, x in v.items():
                 opt(k, x)
             try:
@@ -76,7 +77,7 @@ def main():
         print('%-64s %-46s %s  min %.3f  frac %.3f  diff %s' % (names[vi], json.dumps(v), ' '.join('%.3f' % x for x in t), min(t),
                                                                  alg / (min(t) * 1e-3) / 8e12, diffs.get(vi)))
     for k in KNOBS:
-        opt(k, 0)
+        opt(k, DEFAULTS.get(k, 0))
 
 
 if __name__ == '__main__':

@@ -2,7 +2,7 @@
 usage: python scripts/kernel_resources.py [substring-filter]"""
 import os, re, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
-so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "picha_amd", "libpicha_hip.so")
+so = os.environ.get("PICHA_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "picha_amd", "libpicha_hip.so")
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 with tempfile.TemporaryDirectory() as d:
     fat = os.path.join(d, "fat.bin")

@@ -17,7 +17,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up"):
         set_opt(k, 0)
 
 
@@ -97,6 +97,9 @@ def test_random_resizes_match_oracle(seed):
         set_opt("acc", int(rng.choice([0, 0, 1, 2])))
         set_opt("acc_p2", int(rng.choice([0, 0, 1, 2])))
         set_opt("rows", int(rng.choice([0, 0, 1, 2])))
+        set_opt("xch", int(rng.choice([0, 0, 1, 2])))      # neighbour-exchange forms (r03)
+        set_opt("work", int(rng.choice([0, 0, 1, 2, 3])))  # explicit item list / persistent launch / plain grid (r03)
+        set_opt("up", int(rng.choice([0, 1, 2])))          # upscales on the accumulator kernel or the span kernel (r03)
         try:
             got = picha_amd.resizeSync(img, opts)
         except picha_amd.PichaError as e:
@@ -194,6 +197,9 @@ def test_random_device_batches_match_oracle(seed):
     ftag, fscale = _resize_options(opts)
     r, g, b = color_settings()
     stream = torch.cuda.current_stream().cuda_stream
+    set_opt("work", int(rng.choice([0, 1, 2, 3])))   # item lists / persistent launches index images through the pointer tables
+    set_opt("xch", int(rng.choice([0, 1, 2])))
+    set_opt("up", int(rng.choice([0, 1, 2])))
     if chain_to:
         N.check(L.picha_hip_convert_resize_device(n, S, D, order, r, g, b, ftag, fscale, stream))
     else:

@@ -810,3 +810,94 @@ def test_long_window_accumulator_kernel(pixel):
         got = picha_amd.resizeSync(img, opts)
         assert max_code_diff(got, exp) <= 1, (pixel, sw, "fma", N.lib().picha_hip_last_kernel())
         set_opt("numerics", 0)
+
+
+@pytest.mark.parametrize("work", [1, 2])
+def test_work_item_list_and_persistent_launch_match_oracle(work):
+    """r03: the symmetric-table and accumulator kernels driven by an explicit work-item list (one workgroup per item, short row
+    chunks last) or by a persistent launch (resident workgroups pull items from per-XCD atomic queues).  Every image of a
+    batch large enough for several rounds of items must equal the oracle, for both kernels, with and without the neighbour
+    exchange; the kernel name says which launch form ran."""
+    from picha_amd.device import DeviceBatch, resize_batch
+    import torch
+    suffix = ",items" if work == 1 else ",persistent"
+    cases = [
+        (24, "rgba", 1152, 640, 576, 320, None, {}),                       # sym P3, 2x default
+        (24, "rgba", 1152, 640, 576, 320, None, {"xch": 1}),                # ... neighbour exchange
+        (12, "r16g16b16a16", 1536, 512, 384, 128, "mitchel", {"xch": 1}),   # acc P2 S4 TX15 xch (cfg5's kernel)
+        (12, "r16g16b16a16", 1536, 512, 384, 128, "mitchel", {"xch": 2}),   # plain accumulator kernel
+        (16, "rgb", 1500, 700, 400, 187, None, {}),                         # accumulator kernel, non-integer scale
+    ]
+    try:
+        for n, pixel, sw, sh, dw, dh, filt, opts in cases:
+            for k in ("xch", "row_chunks"):
+                set_opt(k, 0)
+            for k, v in opts.items():
+                set_opt(k, v)
+            set_opt("work", work)
+            set_opt("row_chunks", 6)
+            src = DeviceBatch(n, sw, sh, pixel).fill_random(11 + n)
+            out = resize_batch(src, dw, dh, filter=filt)
+            torch.cuda.synchronize()
+            name = N.lib().picha_hip_last_kernel().decode()
+            # the persistent form falls back to the item list when the list is shorter than two rounds of resident workgroups
+            assert name.endswith(suffix + ">") or (work == 2 and name.endswith(",items>")), name
+            for i in range(n):
+                exp = oracle_resize(src.image_host(i), dw, dh, filt or "cubic", 1.0 if filt else 0.70)
+                assert np.array_equal(out.image_host(i).pixels(), exp.pixels()), (name, i)
+    finally:
+        for k in ("work", "xch", "row_chunks"):
+            set_opt(k, 0)
+
+
+def test_persistent_launch_covers_every_item_of_a_long_list():
+    """A list much longer than the chip holds at once: 384 images x 9 chunks x 2 strip blocks on the persistent form; the
+    digest over the whole batch must equal the plain grid's (every item taken exactly once: a missed item leaves zeros, a
+    doubled one is harmless but the counters would be off for the next launch, so the launch is repeated)."""
+    from picha_amd.device import DeviceBatch, resize_batch
+    import hashlib
+    import torch
+    src = DeviceBatch(384, 1152, 1080, "rgba").fill_random(5)
+    sums = {}
+    try:
+        for work in (3, 2, 2, 1):
+            set_opt("work", work)
+            set_opt("row_chunks", 9)
+            out = resize_batch(src, 576, 540)
+            torch.cuda.synchronize()
+            name = N.lib().picha_hip_last_kernel().decode()
+            sums.setdefault(name, set()).add(hashlib.sha1(out.tensor.cpu().numpy().tobytes()).hexdigest())
+            out.tensor.zero_()
+    finally:
+        set_opt("work", 0)
+        set_opt("row_chunks", 0)
+    assert any(k.endswith(",persistent>") for k in sums) and any(k.endswith(",items>") for k in sums), sums
+    assert len(set.union(*sums.values())) == 1, sums
+
+
+@pytest.mark.parametrize("pixel", ["rgb", "grey", "greya", "rgba", "r16", "r16g16b16"])
+@pytest.mark.parametrize("filt", [None, "cubic", "triangle", "mitchel"])
+def test_integer_upscales_on_the_accumulator_kernel_match_oracle(pixel, filt):
+    """r03: upscales by 2x / 3x run on the accumulator kernel (several outputs per lane sharing one window, 6 / 8 / 12 register
+    accumulators instead of the span kernel's LDS ring); bit-exact, and "up" = 2 gives the span kernel back."""
+    from picha_amd.device import DeviceBatch, resize_batch
+    import torch
+    try:
+        for f in (2, 3):
+            sw, sh = 317, 93
+            src = DeviceBatch(3, sw, sh, pixel).fill_random(7 + f)
+            names = []
+            for up in (1, 2):   # 1: wherever a shape exists (0 = auto takes it for the 16-bit formats only), 2: never
+                set_opt("up", up)
+                out = resize_batch(src, sw * f, sh * f, filter=filt)
+                torch.cuda.synchronize()
+                names.append(N.lib().picha_hip_last_kernel().decode())
+                for i in range(3):
+                    exp = oracle_resize(src.image_host(i), sw * f, sh * f, filt or "cubic", 1.0 if filt else 0.70)
+                    assert np.array_equal(out.image_host(i).pixels(), exp.pixels()), (names[-1], f, i)
+            # "up" = 2: the span kernel (or, for 2-tap windows, the one-output accumulator kernel)
+            assert not (names[1].startswith("resize_acc") and ",S0," in names[1]), names
+            if f == 2 and filt != "triangle":      # triangle at 2x has 2 taps: the one-output accumulator kernel already serves it
+                assert names[0].startswith("resize_acc") and ",S0," in names[0], names
+    finally:
+        set_opt("up", 0)
