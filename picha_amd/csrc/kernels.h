@@ -207,7 +207,8 @@ struct RowsParams {
     int nacc;
     int rows_per_chunk, n_chunks;
 };
-// variant: 0 grey, 1 rgba, 2 rgb -> grey, 3 rgba -> grey, 4 greya, 5 r16g16b16a16 (rows_variant(): -1 if none)
+// variant: 0 grey, 1 rgba, 2 rgb -> grey, 3 rgba -> grey, 4 greya, 5 r16g16b16a16, 6 rgb -> greya, 7 rgba -> greya, 8 r16g16b16 -> r16,
+// 9 r16g16b16a16 -> r16, 10 r16g16b16 -> grey, 11 r16g16b16a16 -> grey (rows_variant(): -1 if none)
 int rows_variant(int src_pixel, int dst_pixel);
 int rows_stage_pixels(int variant);   // source pixels per stage piece
 int rows_window_align(int variant);   // window starts are multiples of this many pixels (8-byte LDS reads)

@@ -60,18 +60,27 @@ hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_
     bool rows_supported_variant##N(int per_lane, int step, int taps);          \
     hipError_t launch_rows_variant##N(const RowsParams &p, hipStream_t s, const char **name);
 PICHA_DECL_ROWS(0) PICHA_DECL_ROWS(1) PICHA_DECL_ROWS(2) PICHA_DECL_ROWS(3) PICHA_DECL_ROWS(4) PICHA_DECL_ROWS(5)
+PICHA_DECL_ROWS(6) PICHA_DECL_ROWS(7) PICHA_DECL_ROWS(8) PICHA_DECL_ROWS(9) PICHA_DECL_ROWS(10) PICHA_DECL_ROWS(11)
 #undef PICHA_DECL_ROWS
+// pixel ids: 0 rgb 1 rgba 2 grey 3 greya 4 r16 5 r16g16 6 r16g16b16 7 r16g16b16a16
 int rows_variant(int sp, int dp) {
     if (sp == dp) return sp == 2 ? 0 : sp == 1 ? 1 : sp == 3 ? 4 : sp == 7 ? 5 : -1;
-    if (dp == 2) return sp == 0 ? 2 : sp == 1 ? 3 : -1;
+    if (dp == 2) return sp == 0 ? 2 : sp == 1 ? 3 : sp == 6 ? 10 : sp == 7 ? 11 : -1;   // -> grey
+    if (dp == 3) return sp == 0 ? 6 : sp == 1 ? 7 : -1;                                  // -> greya
+    if (dp == 4) return sp == 6 ? 8 : sp == 7 ? 9 : -1;                                  // -> r16
     return -1;
 }
-int rows_stage_pixels(int v) { return v == 0 ? 4 : v == 1 ? 1 : v == 2 ? 4 : v == 3 ? 4 : v == 4 ? 2 : 1; }
-int rows_window_align(int v) { return (v == 0 || v == 2 || v == 3) ? 2 : 1; }
+// source pixels per stage piece and window alignment: kernels_rows.hip, rows_stage_px / 8-byte LDS reads of 1-float pixels
+int rows_stage_pixels(int v) {
+    static const int px[12] = {4, 1, 4, 4, 2, 1, 4, 2, 4, 4, 4, 4};
+    return v >= 0 && v < 12 ? px[v] : 1;
+}
+int rows_window_align(int v) { return (v == 0 || v == 2 || v == 3 || v >= 8) ? 2 : 1; }
 bool rows_kernel_supported(int v, int per_lane, int step, int taps) {
     switch (v) {
 #define PICHA_CASE(N) case N: return rows_supported_variant##N(per_lane, step, taps);
     PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5)
+    PICHA_CASE(6) PICHA_CASE(7) PICHA_CASE(8) PICHA_CASE(9) PICHA_CASE(10) PICHA_CASE(11)
 #undef PICHA_CASE
     }
     return false;
@@ -80,6 +89,7 @@ hipError_t launch_resize_rows_kernel(int v, const RowsParams &p, hipStream_t s, 
     switch (v) {
 #define PICHA_CASE(N) case N: return launch_rows_variant##N(p, s, name);
     PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5)
+    PICHA_CASE(6) PICHA_CASE(7) PICHA_CASE(8) PICHA_CASE(9) PICHA_CASE(10) PICHA_CASE(11)
 #undef PICHA_CASE
     }
     return hipErrorInvalidValue;

@@ -30,7 +30,7 @@ constexpr int rows_lds_floats(int ch) { return ch == 3 ? 4 : ch; }   // rgb pixe
 // source pixels a thread stages per piece: whole dwords of source bytes, and (where the format allows) 4 floats = one
 // 16-byte LDS write
 constexpr int rows_stage_px(int src_bpp, int lds_floats) {
-    return lds_floats == 1 ? 4 : (lds_floats == 2 ? 2 : ((src_bpp % 4 == 0) ? 1 : (src_bpp % 2 == 0 ? 2 : 4)));
+    return lds_floats == 1 ? 4 : (lds_floats == 2 ? ((2 * src_bpp) % 4 == 0 ? 2 : 4) : ((src_bpp % 4 == 0) ? 1 : (src_bpp % 2 == 0 ? 2 : 4)));
 }
 
 template <int N> __device__ __forceinline__ void rows_load_dwords(__amdgpu_buffer_rsrc_t rs, uint32_t off, uint32_t *w) {
@@ -316,8 +316,10 @@ hipError_t launch_rows_shape(const RowsParams &p, hipStream_t s, const char **na
 
 // Variants (source format -> resample format), one translation unit each (PICHA_ROWS_VARIANT):
 //   0 grey -> grey   1 rgba -> rgba   2 rgb -> grey (fused colour convert)   3 rgba -> grey (fused)   4 greya -> greya   5 r16g16b16a16
+//   r03, fused colour convert in front of the resample: 6 rgb -> greya   7 rgba -> greya   8 r16g16b16 -> r16   9 r16g16b16a16 -> r16
+//   10 r16g16b16 -> grey   11 r16g16b16a16 -> grey
 #ifndef PICHA_ROWS_VARIANT
-#error "compile with -DPICHA_ROWS_VARIANT=0..5"
+#error "compile with -DPICHA_ROWS_VARIANT=0..11"
 #endif
 #if PICHA_ROWS_VARIANT == 0
 #define ROWS_T 1, false, 1, false
@@ -329,8 +331,20 @@ hipError_t launch_rows_shape(const RowsParams &p, hipStream_t s, const char **na
 #define ROWS_T 4, false, 1, false
 #elif PICHA_ROWS_VARIANT == 4
 #define ROWS_T 2, false, 2, false
-#else
+#elif PICHA_ROWS_VARIANT == 5
 #define ROWS_T 4, true, 4, true
+#elif PICHA_ROWS_VARIANT == 6
+#define ROWS_T 3, false, 2, false
+#elif PICHA_ROWS_VARIANT == 7
+#define ROWS_T 4, false, 2, false
+#elif PICHA_ROWS_VARIANT == 8
+#define ROWS_T 3, true, 1, true
+#elif PICHA_ROWS_VARIANT == 9
+#define ROWS_T 4, true, 1, true
+#elif PICHA_ROWS_VARIANT == 10
+#define ROWS_T 3, true, 1, false
+#else
+#define ROWS_T 4, true, 1, false
 #endif
 #define PICHA_CAT2(a, b) a##b
 #define PICHA_CAT(a, b) PICHA_CAT2(a, b)

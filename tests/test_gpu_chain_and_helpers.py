@@ -54,27 +54,35 @@ def test_convert_resize_chain_equals_two_reference_calls(case, order):
 
 
 FUSED_CASES = [
-    # src pixel, src size, dst size, filter, filterScale: downscales where the fused (row-staged) kernel serves the chain
+    # src pixel, src size, dst size, filter, filterScale[, dst pixel]: downscales where the fused (row-staged) kernel serves the chain
     ("rgb", (960, 270), (128, 64), "lanczos", 1.0),     # cfg3's structure: 7.5x / 4.2x, two outputs per thread
     ("rgb", (1200, 120), (150, 30), "mitchel", 1.0),    # 8x, 31 taps: one output per thread
     ("rgba", (770, 200), (110, 50), "cubic", 0.70),     # rgba -> grey, 7x
     ("rgb", (300, 200), (130, 90), "cubic", 1.0),       # mild non-integer downscale
     ("rgb", (97, 61), (13, 9), "lanczos", 1.0),         # tiny
     ("rgba", (2600, 64), (520, 16), "triangle", 1.0),   # several column strips
+    # r03: the other fused pairs (kernels_rows.hip variants 6-11)
+    ("rgb", (960, 270), (128, 64), "lanczos", 1.0, "greya"),
+    ("rgba", (770, 200), (110, 50), "cubic", 0.70, "greya"),     # alpha carried through the luma pair
+    ("r16g16b16", (640, 180), (96, 40), "mitchel", 1.0, "r16"),
+    ("r16g16b16a16", (900, 126), (120, 30), "lanczos", 1.0, "r16"),   # (120 rows would be an exact 4x: lanczos aliases the ring there)
+    ("r16g16b16", (1200, 90), (150, 30), "cubic", 1.0, "grey"),  # 16-bit source quantised to an 8-bit intermediate
+    ("r16g16b16a16", (640, 96), (160, 24), "catmulrom", 1.0, "grey"),
 ]
 
 
-@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: "%s-%dx%d-%s" % (c[0], c[1][0], c[1][1], c[3]))
+@pytest.mark.parametrize("case", FUSED_CASES, ids=lambda c: "%s-%s-%dx%d-%s" % (c[0], c[5] if len(c) > 5 else "grey", c[1][0], c[1][1], c[3]))
 def test_fused_convert_resize_kernel_equals_two_reference_calls(case):
     """colour convert fused into the resize — the grey intermediate is quantised in registers and
     never exists in HBM — must equal oracle colorConvert followed by oracle resize bit for bit, and equal the two-kernel
     chain (option fuse = 2)."""
-    sp, (sw, sh), (dw, dh), filt, fscale = case
+    sp, (sw, sh), (dw, dh), filt, fscale = case[:5]
+    dpix = case[5] if len(case) > 5 else "grey"
     rng = np.random.default_rng(sw * 7 + dw)
     for weights, wopts in ((None, {}), (picha.color_settings(0.2, 0.7, 0.1), {"redWeight": 0.2, "greenWeight": 0.7, "blueWeight": 0.1})):
         img = rand_image(rng, sw, sh, sp, pad=int(rng.choice([0, 4])), edge_values=bool(weights is not None))
-        want = _chain_oracle(img, "grey", dw, dh, 0, weights, filt, fscale)
-        opts = dict({"pixel": "grey", "width": dw, "height": dh, "filter": filt, "filterScale": fscale}, **wopts)
+        want = _chain_oracle(img, dpix, dw, dh, 0, weights, filt, fscale)
+        opts = dict({"pixel": dpix, "width": dw, "height": dh, "filter": filt, "filterScale": fscale}, **wopts)
         names = {}
         for fuse in (0, 2):
             for chunks in ((0, 1, 3) if fuse == 0 else (0,)):
