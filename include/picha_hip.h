@@ -141,7 +141,9 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "block_waves"  waves per workgroup of the symmetric-table kernel (1..4, 0 = auto)
  *   "sym_sync"   1 = one barrier per step keeps the waves of such a workgroup on the same source rows
  *   "rows"       row-staged LDS downscale kernel: 0 = auto, 1 = whenever it applies, 2 = never
- *   "fuse"       picha_hip_convert_resize*: 0 = one fused kernel where it exists (default), 2 = always two kernels
+ *   "fuse"       picha_hip_convert_resize*: 0 = one fused kernel where it exists and was measured faster (default: every
+ *                convert -> downscale pair of the row-staged kernel; resize -> convert for 16-bit and rgba sources), 1 = one
+ *                kernel wherever an instantiation exists, 2 = always two kernels
  *   "cc_mode"    colour convert layout: 0 = auto, 1 = the 4-pixel kernel, 2 = wide kernel with non-temporal
  *                stores, 3 = store-shaped kernel for expanding pairs
  *   "xcd_remap"  streaming kernels: 0 = auto, 1 = always / 2 = never permute workgroup ids so that each XCD works

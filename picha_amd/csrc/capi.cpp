@@ -777,7 +777,7 @@ int get_rows_strips(DeviceCtx *ctx, DeviceAxis *ax, const DeviceAxis::XTable *xt
     return PICHA_OK;
 }
 
-long g_opt_fuse = 0;  // chained convert+resize: 0 auto (one fused kernel where it exists), 2 always two kernels
+long g_opt_fuse = 0;  // chained convert+resize: 0 auto (one fused kernel where it exists and was measured faster), 1 one kernel wherever it exists, 2 always two kernels
 long g_opt_rows = 0;  // row-staged (LDS) downscale kernel: 0 auto, 1 whenever it applies, 2 never
 
 // Row-staged kernel for one equal-geometry group (kernels_rows.hip): plain downscale (src.pixel == dst.pixel) or colour
@@ -919,11 +919,22 @@ int rows_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, i
 }
 
 // ---- resize of one equal-geometry group on device ------------------------------------------------
+// epi != nullptr: resize followed by a colour convert to dst[].pixel in ONE kernel (accumulator kernel with the convert as a
+// store epilogue); *epi_used says whether that was possible — if not, nothing was launched and the caller chains two kernels.
+struct ChainEpilogue { float r, g, b; bool force; };
+// where the epilogue form is the default (measured r03, profiles/r03_ab_epilogue.txt, 4K sources): 16-bit sources (rgba16 2x down
+// -> rgba: -21 % against resize_sym + convert) and rgba at 2x / 3x (-1 .. -3 %: a tie in time, one intermediate image less in
+// HBM); rgb sources lose 10 % (their two-kernel chain runs the four-outputs-per-lane streaming kernel) and at 4x it is a tie,
+// so those keep the chain.  "fuse" = 1 takes the epilogue wherever it exists.
+bool epilogue_preferred(int pixel, int taps_bucket) {
+    return pixel >= PICHA_R16 || (pixel == PICHA_RGBA && taps_bucket <= 8);
+}
 int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, int filter,
-                 float fscale, hipStream_t s) {
+                 float fscale, hipStream_t s, const ChainEpilogue *epi = nullptr, bool *epi_used = nullptr) {
     const picha_image &s0 = src[0], &d0 = dst[0];
     const int pixel = s0.pixel;
-    {
+    if (epi_used) *epi_used = false;
+    if (!epi) {
         long path;
         { std::lock_guard<std::mutex> lk(g_opt_mu); path = g_opt_path; }
         if (path == 0 || path == 5) {  // "path" = 5: the row-staged kernel or an error
@@ -963,10 +974,14 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     const int ring = std::max(ay->host.span, 1);
     const size_t src_span = image_span(s0), dst_span = image_span(d0);
     bool fused_ok = src_span < (1u << 31) && dst_span < (1u << 31);
-    const int al = fused_align(pixel);
+    const int al = fused_align(pixel), dal = fused_align(d0.pixel);
     for (int i = 0; i < n && fused_ok; ++i) {
         if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) fused_ok = false;
-        if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % al) fused_ok = false;
+        if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % dal) fused_ok = false;
+    }
+    if (epi) {  // only the one-output accumulator kernel carries the epilogue
+        if (!fused_ok || opt_path == 1 || opt_path == 3 || opt_acc == 2 || s0.width < d0.width || s0.height < d0.height) return PICHA_OK;
+        opt_up = 2; opt_xch = 2; opt_acc_p2 = 2; opt_per_lane = 1; opt_path = 4; opt_work = 3;
     }
     int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps, pixel);  // includes alignment room where needed
     const DeviceAxis::XTable *xt = nullptr;
@@ -1282,6 +1297,8 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         }
         acc_per_lane = acc_pl; acc_x_step = acc_step;
     }
+    if (epi && (!yr || acc_long || acc_per_lane != 1 || !acc_epi_supported(pixel, ataps, nacc))) return PICHA_OK;  // caller chains
+    if (epi && !epi->force && !epilogue_preferred(pixel, ataps)) return PICHA_OK;
     if (opt_path == 4 && !yr) return fail(PICHA_ERR_ARGUMENT, "accumulator kernel forced but unsupported for this geometry");
     const bool use_acc = yr != nullptr;
     if (fused_ok && !xt && !use_acc) {
@@ -1325,6 +1342,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         p.ring_slots = ring;
         p.xcd_remap = opt_xcd == 1 ? 1 : 0;
         if (use_acc) { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; p.x_per_lane = acc_per_lane; p.x_step = acc_x_step; p.xch = acc_xch ? 1 : 0; }
+        if (epi) { p.epi_on = 1; p.epi_pixel = d0.pixel; p.epi_r = epi->r; p.epi_g = epi->g; p.epi_b = epi->b; if (epi_used) *epi_used = true; }
         // row chunks: enough waves to fill 256 CUs several times over (~32 K), but every chunk re-resamples the `ring`
         // source rows above its first output: keep that halo under ~6 % of the chunk's own source rows unless the
         // launch would then have fewer than ~8 K waves (4K -> 512x288 thumbnails: 18 -> 6 chunks, -5 %)
@@ -1910,6 +1928,12 @@ int picha_hip_convert_resize_device(int n, const picha_image *src, const picha_i
                            rc = rows_group(ctx, src + i, dst + i, j - i, filter, filter_scale, r, g, b, s, &used);
                            if (rc == PICHA_OK && !used && path == 5)
                                rc = fail(PICHA_ERR_ARGUMENT, "row-staged kernel forced but unsupported for this chain");
+                       }
+                       // resize -> colorConvert: the convert as a store epilogue of the accumulator kernel (r03), where the
+                       // intermediate image would be large (downscales by up to ~4x: tap buckets 5 .. 16)
+                       if (order == PICHA_RESIZE_THEN_CONVERT && fuse != 2 && (path == 0 || path == 4)) {
+                           const ChainEpilogue epi{r, g, b, fuse == 1};
+                           rc = resize_group(ctx, src + i, dst + i, j - i, filter, filter_scale, s, &epi, &used);
                        }
                        return rc != PICHA_OK || used;
                    }()) {

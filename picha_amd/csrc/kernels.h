@@ -99,6 +99,10 @@ struct FusedParams {
     int xch;  // accumulator kernel, neighbour-exchange form: a lane loads only its own x_step * x_per_lane pixels (uniform-base x table)
     WorkList work;  // accumulator kernel only: explicit work items / persistent launch
     int *resident_query;  // host pointer; set: launch nothing, report how many workgroups of this kernel the device holds at once
+    // accumulator kernel, colour-convert epilogue (resize -> colorConvert in one kernel, r03): epi_on != 0: a finished pixel is
+    // packed to the resize's own format, unpacked, channel-mapped and packed to epi_pixel at store time (dst_* describe THAT image)
+    int epi_on, epi_pixel;
+    float epi_r, epi_g, epi_b;
 };
 // Accumulator kernel: instantiations exist for x tap buckets >= 4 and nacc in {4, 6}.  Windows of 37..128 taps go to the
 // long-window variant, which walks the window in segments of acc_long_segment() pixels (64..96 bytes: measured best —
@@ -108,6 +112,7 @@ constexpr int acc_long_segment(int bytes_per_pixel) { return bytes_per_pixel <= 
 bool acc_supported(int pixel, int x_taps_bucket, int nacc);
 bool acc_p2_supported(int pixel, int step, int taps, int nacc);  // two outputs per lane: window of the second `step` pixels after the first
 bool acc_xch_supported(int pixel, int per_lane, int step, int taps, int nacc);  // neighbour-exchange form (dword-sized pixels)
+bool acc_epi_supported(int pixel, int x_taps_bucket, int nacc);  // colour-convert epilogue: one output per lane, tap buckets 4 / 5 / 7 / 8 / 10 / 12 / 16
 bool acc_up_supported(int pixel, int per_lane, int taps, int nacc);  // integer upscales: per_lane outputs share one window of `taps` pixels (step 0)
 hipError_t launch_resize_acc(int pixel, const FusedParams &p, hipStream_t s, const char **kernel_name);
 // True if a fused instantiation exists for this format / tap counts and its LDS ring fits.

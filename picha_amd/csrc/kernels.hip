@@ -179,6 +179,10 @@ bool fused_x_bytespan(int x_taps_bucket, int pixel) {  // aligned fetch: the hos
 bool acc_p2_supported(int pixel, int step, int taps, int nacc) {
     return pixel >= 0 && pixel <= 7 && (nacc == 4 || nacc == 6) && acc_p2_shape(step, taps);
 }
+bool acc_epi_supported(int pixel, int x_taps_bucket, int nacc) {
+    const int t = x_taps_bucket;
+    return acc_supported(pixel, t, nacc) && (t == 4 || t == 5 || t == 7 || t == 8 || t == 10 || t == 12 || t == 16);
+}
 bool acc_up_supported(int pixel, int per_lane, int taps, int nacc) {
     switch (pixel) {
     case 0: return acc_up_shape_ok<3, false>(per_lane, taps, nacc);

@@ -108,6 +108,59 @@ def test_fused_convert_resize_kernel_equals_two_reference_calls(case):
         assert max_code_diff(got, want) <= 1
 
 
+EPILOGUE_CASES = [
+    # src pixel, dst pixel, src size, dst size, filter, filterScale: resize -> colorConvert where the accumulator kernel carries
+    # the convert as a store epilogue (tap buckets 4 / 5 / 7 / 8 / 10 / 12 / 16)
+    ("rgba", "rgb", (640, 360), (320, 180), "cubic", 0.70),          # tiff/png decode -> 2x down -> jpeg's rgb
+    ("rgba", "grey", (600, 300), (200, 100), "cubic", 0.70),         # 3x, 8 taps, luma
+    ("rgb", "grey", (521, 211), (260, 105), "mitchel", 1.0),         # ~2x non-integer, 7..8 taps
+    ("rgb", "rgba", (400, 300), (100, 75), "mitchel", 1.0),          # 4x, 15 taps -> bucket 16, alpha = 1
+    ("greya", "rgba", (334, 100), (160, 50), "cubic", 1.0),          # 2 -> 4 channel map (an odd width would send 2-byte pixels to the two-pass kernels)
+    ("r16g16b16a16", "rgba", (512, 128), (256, 64), "catmulrom", 1.0),   # 16-bit resize, 8-bit result
+    ("r16g16b16a16", "rgb", (480, 96), (160, 32), "cubic", 0.70),
+    ("rgba", "r16g16b16a16", (300, 200), (150, 100), "triangle", 1.0),   # 3 taps -> bucket 5, 8 -> 16 bit
+    ("grey", "greya", (256, 256), (128, 128), "cubic", 0.70),
+]
+
+
+@pytest.mark.parametrize("case", EPILOGUE_CASES, ids=lambda c: "%s-%s-%dx%d-%s" % (c[0], c[1], c[2][0], c[2][1], c[4]))
+def test_resize_then_convert_epilogue_equals_two_reference_calls(case):
+    """SURVEY.md 8f row 2, the other order (r03): resize followed by colorConvert as ONE kernel — the finished pixel is packed to
+    the resize's format, unpacked, channel-mapped and packed to the destination format at store time (src/resize.cc:130 then
+    src/colorconvert.cc:143-150); must equal oracle resize -> oracle colorConvert bit for bit and the two-kernel chain
+    (fuse = 2); fma flavour within one code value."""
+    sp, dp, (sw, sh), (dw, dh), filt, fscale = case
+    rng = np.random.default_rng(sw * 13 + dw)
+    for weights, wopts in ((None, {}), (picha.color_settings(0.25, 0.6, 0.15), {"redWeight": 0.25, "greenWeight": 0.6, "blueWeight": 0.15})):
+        img = rand_image(rng, sw, sh, sp, pad=int(rng.choice([0, 8])), edge_values=bool(weights is not None))  # (8: keeps 8-byte pixels aligned)
+        want = _chain_oracle(img, dp, dw, dh, 1, weights, filt, fscale)
+        opts = dict({"pixel": dp, "width": dw, "height": dh, "filter": filt, "filterScale": fscale, "order": "resizeFirst"}, **wopts)
+        names = {}
+        for fuse in (1, 0, 2):   # 1: the epilogue wherever it exists; 0: the planner's choice (either form); 2: two kernels
+            for chunks in ((0, 1, 3) if fuse == 1 else (0,)):
+                N.check(N.lib().picha_hip_set_option(b"fuse", fuse))
+                N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
+                try:
+                    got = picha.convertResizeSync(img, opts)
+                finally:
+                    for k in (b"fuse", b"row_chunks"):
+                        N.check(N.lib().picha_hip_set_option(k, 0))
+                names[fuse] = N.lib().picha_hip_last_kernel().decode()
+                assert (got.width, got.height, got.pixel) == (dw, dh, dp)
+                assert np.array_equal(payload(got), payload(want)), (case, fuse, chunks, names[fuse], max_code_diff(got, want))
+        assert "epilogue -> " + dp in names[1], names
+        assert " + " in names[2] and "epilogue" not in names[2], names
+        N.check(N.lib().picha_hip_set_option(b"numerics", 1))
+        N.check(N.lib().picha_hip_set_option(b"fuse", 1))
+        try:
+            got = picha.convertResizeSync(img, opts)
+        finally:
+            N.check(N.lib().picha_hip_set_option(b"numerics", 0))
+            N.check(N.lib().picha_hip_set_option(b"fuse", 0))
+        # one code value of the RESIZE's sample type: an 8-bit step is 257 steps of a 16-bit destination
+        assert max_code_diff(got, want) <= (257 if dp.startswith("r16") and not sp.startswith("r16") else 1)
+
+
 ROWS_CASES = [
     ("grey", (960, 270), (128, 64), "lanczos", 1.0),          # cfg3b's structure
     ("grey", (1200, 120), (150, 30), "cubic", 1.0),           # 8x, 31 taps: one output per thread
