@@ -114,15 +114,21 @@ def test_cfg5_full_size_16bit_mitchel():
     n = 3
     src = DeviceBatch(n, 7680, 4320, "r16g16b16a16").fill_random(5)
     sums = {}
-    for path in (0, 4, 3, 1):   # planner's choice, accumulator kernel forced, LDS-ring span kernel, two-pass
+    # planner's choice (r03: the neighbour-exchange accumulator kernel), the one-output accumulator kernel it replaced
+    # (xch = 2), LDS-ring span kernel, two-pass
+    for path, xch in ((0, 0), (4, 2), (3, 0), (1, 0)):
         set_opt("path", path)
+        set_opt("xch", xch)
         out = resize_batch(src, 1920, 1080, filter="mitchel")
         torch.cuda.synchronize()
         name = N.lib().picha_hip_last_kernel().decode()
         if path == 0:
-            assert name.startswith("resize_acc<ch4,u16,TX16,NACC4"), name   # the kernel bench.py times for cfg5
+            assert name.startswith("resize_acc<ch4,u16,P2,S4,TX15,NACC4,exact,xch"), name   # the kernel bench.py times for cfg5
             planner = out
+        if path == 4:
+            assert name.startswith("resize_acc<ch4,u16,TX16,NACC4"), name
         sums[path] = digest(out)
+    set_opt("xch", 0)
     assert len(set(sums.values())) == 1, sums
     for i in (0, n - 1):
         exp = oracle_resize(src.image_host(i), 1920, 1080, "mitchel", 1.0)
@@ -138,7 +144,7 @@ def test_cfg5_per_gpu_batch_of_128_images_kernel_families_agree():
     set_opt("path", 0)
     a = resize_batch(src, 1920, 1080, filter="mitchel")
     torch.cuda.synchronize()
-    assert N.lib().picha_hip_last_kernel().decode().startswith("resize_acc<ch4,u16,TX16,NACC4")
+    assert N.lib().picha_hip_last_kernel().decode().startswith("resize_acc<ch4,u16,P2,S4,TX15,NACC4,exact,xch")   # persistent launch at this size
     da = digest(a)
     set_opt("path", 3)
     b = resize_batch(src, 1920, 1080, filter="mitchel", out=a)   # reuse the destination batch

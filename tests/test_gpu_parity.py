@@ -642,7 +642,8 @@ def test_kernel_selection_for_the_baseline_workloads():
         ("greya", 2304, 96, 768, 32, {}, "resize_sym<ch2,u8,P2,SX3,TX8,SY3,TY8"),
         ("rgba", 384, 216, 192, 108, {"filter": "cubic"}, "resize_stream<ch4,u8,P2,SX2,TX7,SY2,TY7"),     # cfg2, 7 taps
         ("grey", 3840, 216, 512, 51, {"filter": "lanczos"}, "resize_rows<src ch1u8,ch1,u8,P2,S7,TX32"),   # cfg3b (x: 7.5x, y: 4.2x): row-staged kernel
-        ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_acc<ch4,u16,TX16,NACC4"),              # cfg5
+        ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_acc<ch4,u16,P2,S4,TX15,NACC4,exact,xch"),   # cfg5: neighbour-exchange accumulator kernel (r03)
+        ("r16", 320, 180, 640, 360, {}, "resize_acc<ch1,u16,P4,S0,TX5,NACC6"),                           # 16-bit upscale: accumulator kernel, four outputs per lane (r03)
         ("rgb", 384, 216, 192, 108, {}, "resize_stream<ch3,u8,P4,SX2,TX5,SY2,TY5"),
         ("grey", 384, 216, 192, 108, {}, "resize_stream<ch1,u8,P4,SX2,TX5,SY2,TY5"),
         ("rgb", 300, 200, 130, 90, {}, "resize_acc<ch3,u8,TX"),                                          # non-integer scale
