@@ -335,9 +335,9 @@ int get_axis(DeviceCtx *ctx, int filter, float fscale, int src, int dst, std::sh
 // kernel's buffer loads return 0).  fma = 1: weights pre-multiplied by 1/max of the sample type; fma = 2: the
 // reference's weights times 2^22 for kernels that unpack samples as scaled denormals (kernels_impl.inc, Sample::kDen).
 int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps, int fma, int is16,
-               const DeviceAxis::XTable **out, int bytespan_bpp = 0, bool uniform_base = false, int window_align = 0) {
+               const DeviceAxis::XTable **out, int bytespan_bpp = 0, bool uniform_base = false, int window_align = 0, bool overrun = false) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    auto key = std::make_tuple(per_lane, step, taps, fma, is16 + 16 * bytespan_bpp + (uniform_base ? 4096 : 0) + 65536 * window_align);
+    auto key = std::make_tuple(per_lane, step, taps, fma, is16 + 16 * bytespan_bpp + (uniform_base ? 4096 : 0) + (overrun ? 8192 : 0) + 65536 * window_align);
     auto it = ax->xtables.find(key);
     if (it != ax->xtables.end()) { *out = &it->second; return PICHA_OK; }
     DeviceAxis::XTable xt;
@@ -358,7 +358,13 @@ int get_xtable(DeviceCtx *ctx, DeviceAxis *ax, int per_lane, int step, int taps,
     // start before pixel 0 and end past the row (the staged span covers them; those taps have weight 0)
     const int align_px = window_align > 0 ? window_align : bytespan_bpp ? ((bytespan_bpp % 2) ? 4 : 2) : 1;
     int max_left = bytespan_bpp ? t.src_size - taps : INT32_MAX;
-    if (bytespan_bpp) max_left -= ((max_left % align_px) + align_px) % align_px;
+    // the last window may start on the 4-byte boundary at or ABOVE src - taps: it then runs up to align_px - 1 pixels past the end of
+    // the row — the next row's first pixels, or for the last row bytes inside the kernel's dword-rounded descriptor — all under
+    // zero weights (r03; rounding down instead lost the row's last pixels, and such images went to the two-pass kernels)
+    // `overrun` needs every dword load aligned (image bases and strides multiples of 4: the caller checks), so that no load
+    // straddles the descriptor's end; otherwise the last window stays inside the row (rounded down) as before
+    if (bytespan_bpp && overrun) max_left += (align_px - ((max_left % align_px) + align_px) % align_px) % align_px;
+    else if (bytespan_bpp) max_left -= ((max_left % align_px) + align_px) % align_px;
     if (bytespan_bpp && max_left < 0) ok = false;
     // uniform_base: every window starts at step*x + L0 with one L0 for the whole axis (the cross-lane
     // sharing kernel addresses neighbours' pixels by lane distance); left[] then holds L0 in every entry
@@ -975,9 +981,11 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     const size_t src_span = image_span(s0), dst_span = image_span(d0);
     bool fused_ok = src_span < (1u << 31) && dst_span < (1u << 31);
     const int al = fused_align(pixel), dal = fused_align(d0.pixel);
+    bool src_rows4 = true;  // every source row starts on a 4-byte boundary: aligned sub-dword windows may overrun their row (get_xtable)
     for (int i = 0; i < n && fused_ok; ++i) {
         if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) fused_ok = false;
         if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % dal) fused_ok = false;
+        if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % 4) src_rows4 = false;
     }
     if (epi) {  // only the one-output accumulator kernel carries the epilogue
         if (!fused_ok || opt_path == 1 || opt_path == 3 || opt_acc == 2 || s0.width < d0.width || s0.height < d0.height) return PICHA_OK;
@@ -1291,7 +1299,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             }
         }
         if (yr && acc_pl == 1) {
-            rc = get_xtable(ctx, ax, 1, 1, ataps, xw_mode, is16, &xa, (!acc_long && fused_x_bytespan(ataps, pixel)) ? kBytes[pixel] : 0);
+            rc = get_xtable(ctx, ax, 1, 1, ataps, xw_mode, is16, &xa, (!acc_long && fused_x_bytespan(ataps, pixel)) ? kBytes[pixel] : 0, false, 0, src_rows4);
             if (rc) return rc;
             if (!xa->ok) yr = nullptr;
         }
@@ -1304,7 +1312,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (fused_ok && !xt && !use_acc) {
         fused_ok = ktaps > 0 && fused_supported(pixel, ktaps, ay->host.taps, ring, 1);
         if (fused_ok) {
-            rc = get_xtable(ctx, ax, 1, 1, ktaps, xw_mode, is16, &xt, fused_x_bytespan(ktaps, pixel) ? kBytes[pixel] : 0);
+            rc = get_xtable(ctx, ax, 1, 1, ktaps, xw_mode, is16, &xt, fused_x_bytespan(ktaps, pixel) ? kBytes[pixel] : 0, false, 0, src_rows4);
             if (rc) return rc;
             fused_ok = xt->ok;
         }

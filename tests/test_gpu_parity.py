@@ -647,6 +647,8 @@ def test_kernel_selection_for_the_baseline_workloads():
         ("rgb", 384, 216, 192, 108, {}, "resize_stream<ch3,u8,P4,SX2,TX5,SY2,TY5"),
         ("grey", 384, 216, 192, 108, {}, "resize_stream<ch1,u8,P4,SX2,TX5,SY2,TY5"),
         ("rgb", 300, 200, 130, 90, {}, "resize_acc<ch3,u8,TX"),                                          # non-integer scale
+        ("greya", 333, 100, 160, 50, {"filter": "cubic"}, "resize_acc<ch2,u8,TX10"),                     # odd width, 2-byte pixels: aligned windows may overrun the row (r03; was two-pass)
+        ("rgb", 1023, 90, 170, 30, {"filter": "lanczos"}, "resize_acc<ch3,u8,TX"),                       # width not a multiple of 4, long aligned windows (r03; was two-pass)
         ("rgba", 200, 100, 500, 250, {}, "resize_span<ch4,u8,P"),                                        # upscale: ring kernel
     ]
     for pixel, sw, sh, dw, dh, opts, want in cases:
