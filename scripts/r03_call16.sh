@@ -1,0 +1,11 @@
+#!/bin/bash
+o=gpurun_out/r03/call16; mkdir -p $o
+for rnd in 1 2 3 4 5 6; do for lib in picha_amd/libpicha_hip_med3.so picha_amd/libpicha_hip.so; do
+  PICHA_HIP_LIB=$lib timeout -k 10 200 python bench.py --no-cpu-baseline --no-parity --steps 60 --warmup 10 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); print('round $rnd %-28s exact %.4f ms frac %.4f | fma %.4f' % ('$(basename $lib)', d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['other_numerics']['avg_launch_ms']))
+"
+done; done > $o/ab_pack_cfg2_6rounds.txt 2>&1
+cat $o/ab_pack_cfg2_6rounds.txt
