@@ -79,7 +79,9 @@ def test_fused_convert_resize_kernel_equals_two_reference_calls(case):
     sp, (sw, sh), (dw, dh), filt, fscale = case[:5]
     dpix = case[5] if len(case) > 5 else "grey"
     rng = np.random.default_rng(sw * 7 + dw)
-    for weights, wopts in ((None, {}), (picha.color_settings(0.2, 0.7, 0.1), {"redWeight": 0.2, "greenWeight": 0.7, "blueWeight": 0.1})):
+    # default weights, positive custom weights (no clamp needed: the kernel skips it), a negative weight (luma leaves [0, 1]: clamped)
+    for weights, wopts in ((None, {}), (picha.color_settings(0.2, 0.7, 0.1), {"redWeight": 0.2, "greenWeight": 0.7, "blueWeight": 0.1}),
+                           (picha.color_settings(1.6, -0.9, 0.3), {"redWeight": 1.6, "greenWeight": -0.9, "blueWeight": 0.3})):
         img = rand_image(rng, sw, sh, sp, pad=int(rng.choice([0, 4])), edge_values=bool(weights is not None))
         want = _chain_oracle(img, dpix, dw, dh, 0, weights, filt, fscale)
         opts = dict({"pixel": dpix, "width": dw, "height": dh, "filter": filt, "filterScale": fscale}, **wopts)
