@@ -46,6 +46,10 @@ WORKLOADS = {
     "edge_jpeg_thumb_4k_rgb_to_512x288": (192, 3840, 2160, "rgb", 512, 288, {}),                         # jpeg -> thumbnail -> jpeg
     "edge_jpeg_4k_rgb_to_1080p": (192, 3840, 2160, "rgb", 1920, 1080, {}),                               # jpeg -> 1080p -> jpeg
     "cfg5_8k_rgba16_to_1080p_mitchel": (32, 7680, 4320, "r16g16b16a16", 1920, 1080, {"filter": "mitchel"}),
+    # r03: resize -> colorConvert in one kernel (convert as a store epilogue), upscales
+    "edge_deep_png_4k_rgba16_to_1080p_rgba": (32, 3840, 2160, "r16g16b16a16", 1920, 1080, {"convert": "rgba", "chain": True, "order": 1}),  # deep png -> 2x down -> 8-bit
+    "up_960x540_rgba_to_1080p": (64, 960, 540, "rgba", 1920, 1080, {}),
+    "up_960x540_r16_to_1080p": (64, 960, 540, "r16", 1920, 1080, {}),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s achievable copy)
 
@@ -211,7 +215,8 @@ def main():
 
         class _ChainPlan:
             def run(self):
-                convert_resize_batch(src, convert_to, dw, dh, filter=opts.get("filter"), filter_scale=opts.get("filterScale"), out=dst)
+                convert_resize_batch(src, convert_to, dw, dh, filter=opts.get("filter"), filter_scale=opts.get("filterScale"), out=dst,
+                                     order=int(opts.get("order", 0)))
         plan = _ChainPlan()
     elif convert_to:
         from picha_amd.device import color_convert_batch
@@ -285,7 +290,10 @@ def main():
         got = dst.image_host(0)
         filt = opts.get("filter", "cubic")
         fscale = opts.get("filterScale", 1.0 if "filter" in opts else 0.70)
-        if chained:
+        if chained and opts.get("order"):   # resize first, then convert
+            mid, _ = oracle.resize(img.data, sw, sh, pixel, dw, dh, filt, fscale)
+            exp, _ = oracle.color_convert(mid, dw, dh, pixel, convert_to)
+        elif chained:
             mid, _ = oracle.color_convert(img.data, sw, sh, pixel, convert_to)
             exp, _ = oracle.resize(mid, sw, sh, convert_to, dw, dh, filt, fscale)
         elif convert_to:

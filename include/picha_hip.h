@@ -138,6 +138,14 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "xch"        neighbour-exchange form of the symmetric-table / accumulator kernels (a lane loads only the pixels
  *                it owns and takes the rest of its window from the two neighbouring lanes): 0 = auto (measured
  *                table), 1 = wherever an instantiation exists, 2 = never
+ *   "work"       symmetric-table / accumulator kernels: 0 = auto (explicit work-item list for launches of >= 6144 waves,
+ *                persistent launch for the neighbour-exchange accumulator kernel, else the plain 3-D grid), 1 = the list
+ *                (one workgroup per item, short row chunks last), 2 = persistent launch (resident workgroups pull items
+ *                from per-XCD atomic queues), 3 = the plain grid
+ *   "work_tail"  per mille of every XCD's sub-list that is cut into short row chunks (default 200);
+ *   "work_tail_div"  a short chunk = a long chunk / this (default 4)
+ *   "up"         integer upscales on the accumulator kernel (several outputs per lane share one window): 0 = auto (16-bit
+ *                formats), 1 = wherever a shape exists, 2 = never (LDS-ring span kernel)
  *   "block_waves"  waves per workgroup of the symmetric-table kernel (1..4, 0 = auto)
  *   "sym_sync"   1 = one barrier per step keeps the waves of such a workgroup on the same source rows
  *   "rows"       row-staged LDS downscale kernel: 0 = auto, 1 = whenever it applies, 2 = never
@@ -160,9 +168,11 @@ int picha_hip_device_arch(char *buf, size_t len);
 int picha_hip_set_option(const char *key, long value);
 long picha_hip_get_option(const char *key);
 /* Name of the kernel instantiation the last device operation on this thread launched (diagnostics, bench JSON):
- *   "resize_sym<...>"        symmetric-table streaming kernel (",xch": neighbour-exchange form)
+ *   "resize_sym<...>"        symmetric-table streaming kernel (",xch": neighbour-exchange form; ",items" / ",persistent":
+ *                            launched through a work-item list / by persistent workgroups)
  *   "resize_stream<...>"     general streaming kernel (",rot": rotating accumulators), "resize_stream_dpp<...>"
- *   "resize_acc<...>"        accumulator kernel ("P2": two outputs per lane, ",xch"), "resize_acc_long<...>" (> 36 taps)
+ *   "resize_acc<...>"        accumulator kernel ("P2": two outputs per lane, ",xch"; "S0": upscale shape, outputs share one
+ *                            window; ",epilogue -> fmt": colour convert fused in at the store), "resize_acc_long<...>" (> 36 taps)
  *   "resize_rows<...>"       row-staged LDS kernel ("src chN -> chM": colour convert fused in)
  *   "resize_span<...>"       LDS-ring span kernel (upscales, ring-aliasing cases)
  *   "twopass"                hpass_generic + vpass_generic through an HBM scratch

@@ -1208,7 +1208,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 if (cx->c1 - cx->c0 < 2 * 64 * pl) continue;  // needs interior waves to pay
                 // waves per workgroup: small groups backfill the SIMDs sooner (reference arithmetic: VALU + latency bound,
                 // -3..5 %); the memory-bound fma flavour prefers 4 (neighbouring strips share their edge lines in one L1)
-                const int bw = opt_bw > 0 ? (int)std::min<long>(opt_bw, 4) : (fma ? 4 : 2);
+                // (r03: with the explicit work-item list — every launch of >= 6144 waves — the reference arithmetic is as fast with
+                // 4 as with 2, 2.184 vs 2.186 ms on cfg2, and 4 keeps the fabric traffic at 1.09x instead of 1.14x: profiles/r03_ab_work_items.txt)
+                const bool big = (long long)n * ((cx->groups + 63) / 64) * std::max(1, d0.height / 60) >= 6144 && opt_work != 3;
+                const int bw = opt_bw > 0 ? (int)std::min<long>(opt_bw, 4) : (fma || big ? 4 : 2);
                 return launch_stream(pl, cx, cy, 0, false, true, bw, xch);
             }
         }
