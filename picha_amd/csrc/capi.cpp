@@ -1138,7 +1138,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 // short chunks at the end of every sub-list only where a chunk's halo (TY - SY source rows re-filtered) is short:
                 // cfg2 (3 rows) gains 1 % from a 20-25 % tail, cfg5 (11 rows) loses 4 % to it (profiles/r03_ab_work_items.txt)
                 const int tail_pm = (ay->host.taps - sy) <= 2 * sy ? (int)opt_work_tail : 0;
-                int rc2 = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(4, p.rows_per_chunk / (int)opt_work_tail_div), tail_pm, &il);
+                int rc2 = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(16, p.rows_per_chunk / (int)opt_work_tail_div), tail_pm, &il);
                 if (rc2) return rc2;
                 p.n_images = n;
                 p.work.items = il->items; p.work.items_per_xcd = il->per_xcd;
@@ -1376,7 +1376,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             const DeviceCtx::ItemList *il = nullptr;
             const double src_per_out = std::max(1.0, (double)s0.height / d0.height);
             const int tail_pm = ring <= 2 * src_per_out ? (int)opt_work_tail : 0;   // as above: only where the halo is short
-            rc = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(4, p.rows_per_chunk / (int)opt_work_tail_div), tail_pm, &il);
+            rc = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(16, p.rows_per_chunk / (int)opt_work_tail_div), tail_pm, &il);
             if (rc) return rc;
             p.work.items = il->items; p.work.items_per_xcd = il->per_xcd;
             if (work_mode == 2) {
