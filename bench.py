@@ -83,7 +83,7 @@ def _host_threads():
         return max(1, os.cpu_count() or 1)
 
 
-def cpu_baseline(name, budget_images=256):
+def cpu_baseline(name):
     """The oracle (CPU port of reference src/resize.cc:66-134, specialised per pixel format like the reference's templates) on
     a bounded sample of the workload, at 1 thread, at 4 threads (libuv's default pool size = the reference's real async
     concurrency) and on every host core this process may run on."""
@@ -109,10 +109,11 @@ def cpu_baseline(name, budget_images=256):
         return {"value": round(n_img * sw * sh / dt / 1e6, 2), "cores": nthreads,
                 "sample": "%d images (%d distinct), one image per thread on %d thread(s), %.2f s wall" % (n_img, distinct, nthreads, dt)}
 
-    # about 10-30 s of CPU work in total: 2-4 images per thread on all cores
-    n_all = threads * 2 if big else max(threads, min(budget_images, threads * 4))
-    one = run(1, 2 if big else 8)
-    four = run(min(4, threads), 4 if big else 16)
+    # about 10-30 s of CPU work in total (a 4K image is ~35-90 ms of one core): 24 images on one thread, 48 on four, two per
+    # thread on all cores (at most 512: the destination images of one run are all live)
+    n_all = threads * 2 if big else max(threads, min(512, threads * 2))
+    one = run(1, 2 if big else 24)
+    four = run(min(4, threads), 4 if big else 48)
     full = run(threads, n_all)
     out = {
         "value": full["value"],
