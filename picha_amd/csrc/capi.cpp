@@ -20,6 +20,7 @@
 
 #include "../../include/picha_hip.h"
 #include "kernels.h"
+#include "lane_pool.h"
 #include "taps.h"
 
 using namespace picha_hip;
@@ -1494,26 +1495,16 @@ int convert_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst
 
 // Host-pointer entry points: stream + pinned staging buffer + device arena travel together as one "lane", leased from
 // a per-device pool for the duration of a call.  (They used to be thread_local and were never freed: a service
-// that spawns a thread per request leaked ~50 MB pinned + ~50 MB HBM per dead thread.)  The pool keeps as many idle lanes
-// as callers were ever inside a call at once (at least kMinIdleLanes) as long as their memory stays under a byte budget:
-// a steady pool of N worker threads therefore never creates or frees a lane after warm-up — hipFree / hipHostFree are
-// device-wide synchronisations and would stall the async dispatchers' streams.  Lanes beyond that (a burst larger than
-// anything seen before, or over the budget) are retired lazily: they are parked and destroyed by a later acquire() once
-// they have been idle for kLaneIdleSeconds, never on a call's return path.
+// that spawns a thread per request leaked ~50 MB pinned + ~50 MB HBM per dead thread.)  The leasing policy — how many idle
+// lanes are kept, when and by whom surplus ones are destroyed — is lane_pool.h (run under TSan / ASan by tests/sanitize).
 struct HostLane {
     hipStream_t s = nullptr;
     uint8_t *pinned = nullptr; size_t pinned_cap = 0;
     uint8_t *arena = nullptr;  size_t arena_cap = 0;
     std::chrono::steady_clock::time_point idle_since;
+    size_t held_bytes() const { return pinned_cap; }   // (and as many device bytes)
 };
-struct LanePool {
-    std::mutex mu;
-    std::vector<HostLane *> idle;  // most recently used at the back
-    size_t in_use = 0, peak_in_use = 0;
-};
-constexpr size_t kMinIdleLanes = 16;
-constexpr size_t kLaneBudgetBytes = (size_t)4 << 30;  // pinned bytes (and as many device bytes) the idle lanes may hold
-constexpr int kLaneIdleSeconds = 10;
+using LanePool = LanePoolT<HostLane>;
 std::mutex g_lane_mu;
 std::map<int, LanePool *> g_lane_pools;  // never destroyed: static destruction order vs. the HIP runtime
 
@@ -1529,50 +1520,24 @@ void lane_destroy(HostLane *l) {  // errors ignored: also runs at teardown
     if (l->arena) (void)hipFree(l->arena);
     delete l;
 }
-// lanes the pool no longer wants (caller holds pool->mu): idle for a while AND surplus to the peak concurrency or the budget
-void lane_collect_surplus(LanePool *pool, std::vector<HostLane *> *out) {
-    const auto now = std::chrono::steady_clock::now();
-    const size_t keep = std::max(kMinIdleLanes, pool->peak_in_use);
-    size_t bytes = 0;
-    for (HostLane *l : pool->idle) bytes += l->pinned_cap;
-    size_t i = 0;  // oldest first
-    while (i < pool->idle.size() && (pool->idle.size() + pool->in_use > keep || bytes > kLaneBudgetBytes)) {
-        HostLane *l = pool->idle[i];
-        if (std::chrono::duration_cast<std::chrono::seconds>(now - l->idle_since).count() < kLaneIdleSeconds) { ++i; continue; }
-        bytes -= l->pinned_cap;
-        out->push_back(l);
-        pool->idle.erase(pool->idle.begin() + (long)i);
-    }
-}
 struct LaneLease {
     int dev = -1;
     HostLane *lane = nullptr;
     ~LaneLease() {
-        if (!lane) return;
-        LanePool *pool = lane_pool(dev);
-        lane->idle_since = std::chrono::steady_clock::now();
-        std::lock_guard<std::mutex> lk(pool->mu);  // nothing is freed here: see lane_collect_surplus
-        pool->idle.push_back(lane);
-        --pool->in_use;
+        if (lane) lane_pool(dev)->give(lane);   // nothing is freed on a call's return path
     }
     int acquire(int device) {
         dev = device;
         LanePool *pool = lane_pool(dev);
         std::vector<HostLane *> surplus;
-        {
-            std::lock_guard<std::mutex> lk(pool->mu);
-            if (!pool->idle.empty()) { lane = pool->idle.back(); pool->idle.pop_back(); }
-            ++pool->in_use;
-            pool->peak_in_use = std::max(pool->peak_in_use, pool->in_use);
-            lane_collect_surplus(pool, &surplus);
-        }
-        for (HostLane *l : surplus) lane_destroy(l);  // rare: only lanes idle for kLaneIdleSeconds beyond what the pool keeps
+        lane = pool->take(&surplus);
+        for (HostLane *l : surplus) lane_destroy(l);  // rare: lanes idle for 10 s beyond what the pool keeps
         if (!lane) {
             lane = new HostLane;
             hipError_t e = hipStreamCreateWithFlags(&lane->s, hipStreamNonBlocking);
             if (e != hipSuccess) {
                 delete lane; lane = nullptr;
-                { std::lock_guard<std::mutex> lk(pool->mu); --pool->in_use; }
+                pool->cancel();
                 return fail(PICHA_ERR_HIP, "hipStreamCreate failed: %s", hipGetErrorString(e));
             }
         }

@@ -38,3 +38,12 @@ def test_async_dispatcher_logic_under_sanitizers(tmp_path, san):
     # singletons by design — freeing HIP resources from static destructors races the runtime's own teardown
     _build_and_run(tmp_path, "dispatch_" + san.split(",")[0], [os.path.join(SAN, "dispatch_harness.cpp"), os.path.join(CSRC, "dispatch.cpp")], flags,
                    leaks=False)
+
+
+@pytest.mark.parametrize("san", ["thread", "address,undefined"])
+def test_lane_pool_policy_under_sanitizers(tmp_path, san):
+    """picha_amd/csrc/lane_pool.h (r03): the leasing policy of the host entry points' stream / staging / arena pool
+    with a dummy lane type — exclusive leases, no frees on the return path, no more lanes than concurrent callers, lazy
+    retirement through take()."""
+    flags = ["-fsanitize=" + san] + (["-fno-sanitize-recover=undefined"] if "undefined" in san else [])
+    _build_and_run(tmp_path, "lane_pool_" + san.split(",")[0], [os.path.join(SAN, "lane_pool_harness.cpp")], flags)
