@@ -143,6 +143,15 @@ struct DeviceAxis {
         int n_strips = 0, pieces = 0;  // stage pieces per thread and row (1, 2, 4, 8)
     };
     std::map<std::tuple<const void *, int, int>, RowsStrips> rows_strips;
+    // run kernel, x role: the period's canonical weights and the columns that do not have them
+    struct RunTable {
+        bool ok = false;
+        void *blob = nullptr;
+        float *canon = nullptr;        // [period][taps]
+        int c0 = 0, c1 = 0;            // columns [c0, c1) have the canonical weights
+        int x_base = 0, taps = 0;
+    };
+    std::map<std::tuple<int, int, int, int>, RunTable> runtables;
 
     DeviceAxis() = default;
     DeviceAxis(const DeviceAxis &) = delete;
@@ -153,6 +162,7 @@ struct DeviceAxis {
         for (auto &kv : ystreams) if (kv.second.blob) (void)hipFree(kv.second.blob);
         for (auto &kv : yrows) if (kv.second.blob) (void)hipFree(kv.second.blob);
         for (auto &kv : rows_strips) if (kv.second.blob) (void)hipFree(kv.second.blob);
+        for (auto &kv : runtables) if (kv.second.blob) (void)hipFree(kv.second.blob);
     }
     // fused, y role
     int4 *y_info = nullptr;
@@ -549,6 +559,73 @@ int get_yrows(DeviceCtx *ctx, DeviceAxis *ay, int nacc, const DeviceAxis::YRows 
     return PICHA_OK;
 }
 
+// Run kernel (kernels_run.hip), x role.  The table is periodic with `period` outputs / `period_px` source pixels when, for the
+// canonical window start  c(x) = x_base + (x / period) * period_px + ((x % period) * period_px) / period,  every output's taps lie
+// inside [c(x), c(x) + taps) and its zero-padded weights equal those of the middle period's output x % period bit for bit.  Columns
+// that fail (windows clipped by an image edge carry renormalised weights) must be a few at either end of the row — [0, c0) and
+// [c1, dst), at most kMaxRunEdge each — which the kernel computes one pixel per lane from the generic tables.  `pad_to` > 0: pad the window to that many taps (an instantiated count).
+// wmode: 0 reference weights, 1 times 1/max (fma flavour), 2 times 2^22 (formats that unpack through the denormal form).
+constexpr int kMaxRunEdge = 16;
+int run_table_taps(const AxisTaps &t, int period, int period_px, int *x_base_out) {
+    const int dst = t.dst_size;
+    if (dst < 4 * period) return 0;
+    auto offg = [&](int x) { return (x / period) * period_px + ((x % period) * period_px) / period; };
+    const int mid = (dst / 2) / period * period;
+    int xb = INT32_MAX, tx = 0;
+    for (int q = 0; q < period; ++q) xb = std::min(xb, t.left[mid + q] - offg(mid + q));
+    for (int q = 0; q < period; ++q) tx = std::max(tx, t.left[mid + q] - (xb + offg(mid + q)) + t.count[mid + q]);
+    *x_base_out = xb;
+    return tx;
+}
+int get_runtable(DeviceCtx *ctx, DeviceAxis *ax, int period, int period_px, int pad_to, int wmode, int is16, const DeviceAxis::RunTable **out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    auto key = std::make_tuple(period, period_px, pad_to, wmode + 4 * is16);
+    auto it = ax->runtables.find(key);
+    if (it != ax->runtables.end()) { *out = &it->second; return PICHA_OK; }
+    DeviceAxis::RunTable rt;
+    const AxisTaps &t = ax->host;
+    const int dst = t.dst_size, T = t.taps;
+    int xb = 0;
+    const int tx_min = run_table_taps(t, period, period_px, &xb);
+    const int TX = std::max(tx_min, pad_to);
+    bool ok = tx_min > 0 && TX <= 64;
+    std::vector<float> canon;
+    int c0 = 0, c1 = dst;
+    if (ok) {
+        auto offg = [&](int x) { return (x / period) * period_px + ((x % period) * period_px) / period; };
+        const float inv = is16 ? 1.0f / 65535.0f : 1.0f / 255.0f;
+        auto padded = [&](int x, float *v) {  // false: the taps do not fit the canonical window
+            const int first = t.left[x] - (xb + offg(x));
+            if (first < 0 || first + t.count[x] > TX) return false;
+            for (int j = 0; j < TX; ++j) v[j] = 0.0f;
+            for (int j = 0; j < t.count[x]; ++j) {
+                const float w = t.weight[(size_t)x * T + j];
+                v[first + j] = wmode == 1 ? w * inv : wmode == 2 ? w * 4194304.0f : w;
+            }
+            return true;
+        };
+        const int mid = (dst / 2) / period * period;
+        canon.assign((size_t)period * TX, 0.0f);
+        for (int q = 0; q < period && ok; ++q) ok = padded(mid + q, &canon[(size_t)q * TX]);
+        std::vector<float> v(TX);
+        auto is_canon = [&](int x) { return padded(x, v.data()) && memcmp(v.data(), &canon[(size_t)(x % period) * TX], sizeof(float) * TX) == 0; };
+        while (ok && c0 < dst && !is_canon(c0)) ++c0;
+        while (ok && c1 > c0 && !is_canon(c1 - 1)) --c1;
+        for (int x = c0; x < c1 && ok; ++x) ok = is_canon(x);
+        if (c0 > kMaxRunEdge || dst - c1 > kMaxRunEdge || c1 - c0 < 2 * period) ok = false;
+    }
+    rt.ok = ok;
+    if (ok) {
+        HIP_TRY(hipMalloc(&rt.blob, sizeof(float) * canon.size()));
+        HIP_TRY(hipMemcpy(rt.blob, canon.data(), sizeof(float) * canon.size(), hipMemcpyHostToDevice));
+        rt.canon = static_cast<float *>(rt.blob);
+        rt.c0 = c0; rt.c1 = c1; rt.x_base = xb; rt.taps = TX;
+    }
+    auto ins = ax->runtables.emplace(key, rt);
+    *out = &ins.first->second;
+    return PICHA_OK;
+}
+
 // ---- validation ----------------------------------------------------------------------------------
 int check_src(const picha_image *im) {
     // jsImageToNativeImage (src/picha.cc:61-85): valid pixel, data present, height != 0
@@ -787,6 +864,243 @@ int get_rows_strips(DeviceCtx *ctx, DeviceAxis *ax, const DeviceAxis::XTable *xt
 long g_opt_fuse = 0;  // chained convert+resize: 0 auto (one fused kernel where it exists and was measured faster), 1 one kernel wherever it exists, 2 always two kernels
 long g_opt_rows = 0;  // row-staged (LDS) downscale kernel: 0 auto, 1 whenever it applies, 2 never
 
+long g_opt_run = 0;   // run kernel (periodic tap tables, kernels_run.hip): 0 auto, 1 whenever it applies, 2 never
+
+// Run kernel for one equal-geometry group: downscales whose x scale is a ratio of small integers with a long window.
+// *used = false: not applicable, the caller goes on with the other kernels.
+int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, int filter, float fscale, hipStream_t s, bool *used) {
+    *used = false;
+    const picha_image &s0 = src[0], &d0 = dst[0];
+    const int pixel = s0.pixel;
+    long opt_run, opt_numerics, opt_chunks, opt_per_lane, opt_work, opt_work_tail, opt_work_tail_div, opt_bw;
+    {
+        std::lock_guard<std::mutex> lk(g_opt_mu);
+        opt_run = g_opt_run; opt_numerics = g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
+        opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
+        opt_bw = g_opt_block_waves;
+    }
+    if (opt_run == 2 || s0.pixel != d0.pixel) return PICHA_OK;
+    if (d0.width >= s0.width || d0.height >= s0.height) return PICHA_OK;  // downscales only
+    const size_t src_span = image_span(s0), dst_span = image_span(d0);
+    if (src_span >= (1u << 30) || dst_span >= (1u << 30)) return PICHA_OK;
+    const int al = fused_align(pixel);
+    for (int i = 0; i < n; ++i) {
+        if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) return PICHA_OK;
+        if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % 4) return PICHA_OK;  // a lane stores its run as whole dwords
+        if (src[i].stride % 4) return PICHA_OK;  // the edge pass fetches a block of rows at one byte phase
+    }
+    // the period: scale = period_px / period in lowest terms
+    int g = s0.width, b = d0.width;
+    while (b) { const int t = g % b; g = b; b = t; }
+    const int period = d0.width / g, period_px = s0.width / g;
+    if (period > 4) return PICHA_OK;
+    std::shared_ptr<DeviceAxis> ax_ref, ay_ref;
+    int rc = get_axis(ctx, filter, fscale, s0.width, d0.width, &ax_ref);
+    if (rc) return rc;
+    rc = get_axis(ctx, filter, fscale, s0.height, d0.height, &ay_ref);
+    if (rc) return rc;
+    DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
+    int xb = 0;
+    const int tx_min = run_table_taps(ax->host, period, period_px, &xb);
+    if (tx_min <= 0) return PICHA_OK;
+    const int fma = opt_numerics == 1 ? 1 : 0;
+    const int is16 = pixel >= PICHA_R16;
+    const int wmode = fma ? 1 : exact_unpack_scaled(kChannels[pixel], is16 != 0) ? 2 : 0;
+    // shape: the smallest instantiated tap count >= the table's, outputs per lane as instantiated ("per_lane" forces one)
+    const DeviceAxis::YRows *yr = nullptr;
+    int nacc = 0, per_lane = 0, ktaps = 0;
+    for (int na : {4, 6}) {
+        const DeviceAxis::YRows *cand = nullptr;
+        rc = get_yrows(ctx, ay, na, &cand);
+        if (rc) return rc;
+        if (cand->ok) { yr = cand; nacc = na; break; }
+    }
+    if (!yr) return PICHA_OK;
+    // outputs per lane: four for single-channel pixels, two for the others (r03 survey, profiles/r03_survey_run_kernel.txt)
+    static const int order1[] = {4, 8, 2}, order2[] = {2, 4, 8};
+    for (int tx = tx_min; tx <= tx_min + 3 && !per_lane; ++tx)
+        for (int pl : (kChannels[pixel] == 1 ? order1 : order2)) {
+            if (opt_per_lane > 0 && pl != opt_per_lane) continue;
+            if (pl % period || !run_kernel_supported(pixel, period, period_px, tx, pl, nacc)) continue;
+            per_lane = pl; ktaps = tx;
+            break;
+        }
+    if (!per_lane) return PICHA_OK;
+    // where it is the default (same survey): windows of 26 taps and more (cfg3b: -3 % reference arithmetic, -10 % fma against the
+    // row-staged kernel; greya -35 %); shorter windows only for batches that still fill the chip with a quarter of the
+    // accumulator kernel's waves (256 x 4K -> 512x288 grey: -11 %; 128 images: a tie)
+    if (opt_run == 0 && ktaps < 26 && !(kChannels[pixel] == 1 && n >= 192)) return PICHA_OK;
+    const DeviceAxis::RunTable *rt = nullptr;
+    rc = get_runtable(ctx, ax, period, period_px, ktaps, wmode, is16, &rt);
+    if (rc) return rc;
+    if (!rt->ok) return PICHA_OK;
+
+    // edge columns: recomputed by resize_edges_kernel from a stash of the raw dwords of the two lanes that hold them (kernels_run.hip)
+    const int x_groups = (d0.width + per_lane - 1) / per_lane;
+    const bool has_edges = rt->c0 > 0 || rt->c1 < d0.width;
+    int stash_words = 0, stash_org[2] = {0, 0};
+    if (has_edges) {
+        const int bpp = kBytes[pixel];
+        const int span = ((per_lane - 1) / period) * period_px + (((per_lane - 1) % period) * period_px) / period + ktaps;  // RunCfg::SPAN
+        stash_words = bpp % 4 == 0 ? span * bpp / 4 : (span * bpp + 3) / 4 + 1;                                        // RunCfg::NW
+        if (x_groups < 2) return PICHA_OK;
+        for (int i = 0; i < n; ++i)
+            if ((uintptr_t)src[i].data % 4) return PICHA_OK;  // the stash is laid out for lane windows that start on a dword of the row
+        const int g_last = (d0.width - 1) / per_lane;
+        for (int side = 0; side < 2; ++side) {
+            const int g = side == 0 ? 0 : g_last;
+            const int ws = rt->x_base + g * (per_lane / period) * period_px;   // first pixel of the lane's window
+            const int org = (ws * bpp) & ~3;
+            stash_org[side] = org;
+            const int xa = side == 0 ? 0 : rt->c1, xb = side == 0 ? rt->c0 : d0.width;
+            if (side == 0 ? rt->c0 > per_lane : rt->c1 < g_last * per_lane) return PICHA_OK;   // the side's columns all belong to that lane
+            for (int x = xa; x < xb; ++x) {
+                const int bo = ax->host.left[x] * bpp - org;
+                if (bo < 0 || bo + ax->host.count[x] * bpp > stash_words * 4) return PICHA_OK;
+            }
+        }
+    }
+    int edge_rows = 0;
+    {   // blocks of the edge pass (kernels_run.hip, edge_pass): x weights + y weights + horizontal sums <= 2048 floats (kEdgeFloats)
+        const int ncol = std::max(1, std::max(rt->c0, d0.width - rt->c1));   // one side per wave
+        const int txe = (ktaps + 3) / 4 * 4;
+        const int ch = kChannels[pixel];
+        // source rows a block of `rows` output rows spans at most, exactly as the kernel derives them from the march's range table
+        // (first row needed by the block's first output row or any later one .. last row needed so far)
+        const AxisTaps &ty = ay->host;
+        std::vector<int> first(d0.height), last(d0.height);
+        for (int y = 0; y < d0.height; ++y) { first[y] = ty.left[y]; last[y] = ty.left[y] + ty.count[y] - 1; }
+        for (int y = d0.height - 2; y >= 0; --y) first[y] = std::min(first[y], first[y + 1]);
+        for (int y = 1; y < d0.height; ++y) last[y] = std::max(last[y], last[y - 1]);
+        auto max_rows = [&](int rows) {
+            int m = 0;
+            for (int ya = 0; ya < d0.height; ya += rows) m = std::max(m, last[std::min(d0.height, ya + rows) - 1] - first[ya] + 1);
+            return m;
+        };
+        int er = std::min(64, d0.height);
+        auto floats = [&](int rows) { return ncol * txe + rows * ty.taps + ncol * ch * max_rows(rows); };
+        while (er > 1 && floats(er) > 2048) --er;
+        if (floats(er) > 2048) return PICHA_OK;
+        edge_rows = er;
+    }
+    RunParams p{};
+    long long sp = 0, dp = 0;
+    TablePair tab;
+    std::unique_lock<std::mutex> temp_lock(ctx->temp_mu, std::defer_lock);
+    if (uniform_pitch(src, n, &sp) && uniform_pitch(dst, n, &dp)) {
+        p.src = static_cast<const uint8_t *>(s0.data);
+        p.dst = static_cast<uint8_t *>(d0.data);
+        p.src_pitch = sp; p.dst_pitch = dp;
+    } else {
+        temp_lock.lock();
+        rc = make_tables(ctx, src, dst, n, s, &tab);
+        if (rc) return rc;
+        p.src_tab = tab.src; p.dst_tab = tab.dst;
+    }
+    bool stash_used = false;
+    auto release_temps = [&]() {
+        int r1 = PICHA_OK, r2 = PICHA_OK;
+        if (tab.used) r1 = temp_release(ctx->tables, s);
+        if (stash_used) r2 = temp_release(ctx->scratch, s);
+        return r1 ? r1 : r2;
+    };
+    if (has_edges && opt_run != 3) {
+        const size_t bytes = (size_t)n * 2 * s0.height * stash_words * 4;
+        if (bytes >= ((size_t)1 << 32)) { (void)release_temps(); return PICHA_OK; }
+        if (!temp_lock.owns_lock()) temp_lock.lock();
+        rc = temp_acquire(ctx->scratch, bytes, 0, s);
+        if (rc) { (void)release_temps(); return rc; }
+        stash_used = true;
+        p.stash = static_cast<uint32_t *>(ctx->scratch.dev);
+        p.stash_words = stash_words; p.stash_org[0] = stash_org[0]; p.stash_org[1] = stash_org[1];
+    }
+    p.src_stride = s0.stride; p.dst_stride = d0.stride;
+    p.src_w = s0.width; p.src_h = s0.height; p.dst_w = d0.width; p.dst_h = d0.height;
+    p.src_bytes = (unsigned)src_span; p.dst_bytes = (unsigned)dst_span;
+    p.period = period; p.period_px = period_px; p.x_taps = ktaps; p.x_per_lane = per_lane; p.x_base = rt->x_base;
+    p.x_groups = x_groups;
+    p.x_canon = rt->canon;
+    p.fma = fma;
+    p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc;
+    p.cx0 = rt->c0; p.cx1 = rt->c1;
+    if (opt_run == 3) { p.cx0 = 0; p.cx1 = d0.width; }  // measurement only: no edge pass (the edge columns come out wrong)
+    p.edge_rows = edge_rows;
+    p.x_left = ax->left; p.x_count = ax->count; p.x_weight = ax->weight; p.x_wtaps = ax->host.taps;
+    p.y_count = ay->count; p.y_eff = ay->eff; p.y_weight = ay->weight; p.y_taps = ay->host.taps;
+    const int col_waves = (p.x_groups + 63) / 64;
+    p.block_waves = opt_bw >= 1 && opt_bw <= 4 ? (int)opt_bw : std::min(4, col_waves);
+    const int nsb = (col_waves + p.block_waves - 1) / p.block_waves;
+    // row chunks: as for the accumulator kernel (>= ~8 K waves, the re-resampled halo of a chunk under ~6 % of its rows)
+    const int ring = std::max(ay->host.span, 1);
+    long long chunks = opt_chunks > 0 ? opt_chunks : (32768 + (long long)n * col_waves - 1) / ((long long)n * col_waves);
+    if (opt_chunks <= 0) {
+        const double src_rows_per_out = std::max(1.0, (double)s0.height / d0.height);
+        const long long min_rows = (long long)std::ceil(ring / (0.06 * src_rows_per_out));
+        const long long by_halo = std::max<long long>(1, d0.height / std::max<long long>(16, min_rows));
+        const long long by_fill = (8192 + (long long)n * col_waves - 1) / ((long long)n * col_waves);
+        chunks = std::min(chunks, std::max(by_halo, by_fill));
+    }
+    chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
+    p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
+    p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
+    auto fail_launch = [&](hipError_t e) {
+        (void)release_temps();
+        return fail(PICHA_ERR_HIP, "run-kernel resize launch failed: %s", hipGetErrorString(e));
+    };
+    // launch form: the plain grid (measured r03 on cfg3b: item list +3 %, persistent +30 %; the edge kernel follows either way)
+    const int work_mode = opt_work == 1 || opt_work == 2 ? (int)opt_work : 0;
+    if (work_mode) {
+        const DeviceCtx::ItemList *il = nullptr;
+        rc = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(16, p.rows_per_chunk / (int)opt_work_tail_div), (int)opt_work_tail, &il);
+        if (rc) { (void)release_temps(); return rc; }
+        p.n_images = n;
+        p.work.items = il->items; p.work.items_per_xcd = il->per_xcd;
+        if (work_mode == 2) {
+            const int resident = run_kernel_resident_blocks(pixel, p);
+            if (resident > 0 && (long long)il->per_xcd * 8 > 2LL * resident) {
+                rc = get_queue(ctx, s, &p.work.queue);
+                if (rc) { (void)release_temps(); return rc; }
+                p.n_chunks = resident / 8 * 8;
+            }
+        }
+        hipError_t e = launch_resize_run_kernel(pixel, p, s, &g_last_kernel);
+        if (e != hipSuccess) return fail_launch(e);
+        int done = 0;
+        while (done < n) {  // grid.z limit of the edge kernel
+            const int m = std::min(n - done, 65535);
+            RunParams q = p;
+            q.n_images = m;
+            if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
+            else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
+            q.stash_img0 = done;
+            e = launch_resize_edges_kernel(pixel, q, s);
+            if (e != hipSuccess) return fail_launch(e);
+            done += m;
+        }
+    } else {
+        int done = 0;
+        while (done < n) {  // grid.z limit
+            const int m = std::min(n - done, 65535);
+            RunParams q = p;
+            q.n_images = m;
+            if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
+            else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
+            q.stash_img0 = done;
+            hipError_t e = launch_resize_run_kernel(pixel, q, s, &g_last_kernel);
+            if (e == hipSuccess) e = launch_resize_edges_kernel(pixel, q, s);
+            if (e != hipSuccess) return fail_launch(e);
+            done += m;
+        }
+    }
+    if (p.stash) {
+        static thread_local char name[192];
+        snprintf(name, sizeof name, "%s + resize_edges<%d columns>", g_last_kernel ? g_last_kernel : "", p.cx0 + (d0.width - p.cx1));
+        g_last_kernel = name;
+    }
+    *used = true;
+    return release_temps();
+}
+
 // Row-staged kernel for one equal-geometry group (kernels_rows.hip): plain downscale (src.pixel == dst.pixel) or colour
 // convert fused in front (src.pixel != dst.pixel: the result equals colorConvert followed by resize, the intermediate
 // quantised in registers).  *used = false: not applicable, the caller goes on with the other kernels.
@@ -942,8 +1256,14 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     const int pixel = s0.pixel;
     if (epi_used) *epi_used = false;
     if (!epi) {
-        long path;
-        { std::lock_guard<std::mutex> lk(g_opt_mu); path = g_opt_path; }
+        long path, rows_forced;
+        { std::lock_guard<std::mutex> lk(g_opt_mu); path = g_opt_path; rows_forced = g_opt_rows == 1; }
+        if ((path == 0 && !rows_forced) || path == 6) {  // "path" = 6: the run kernel or an error
+            bool used = false;
+            int rcr = run_group(ctx, src, dst, n, filter, fscale, s, &used);
+            if (rcr || used) return rcr;
+            if (path == 6) return fail(PICHA_ERR_ARGUMENT, "run kernel forced but unsupported for this geometry");
+        }
         if (path == 0 || path == 5) {  // "path" = 5: the row-staged kernel or an error
             bool used = false;
             int rcr = rows_group(ctx, src, dst, n, filter, fscale, 0.0f, 0.0f, 0.0f, s, &used);
@@ -1760,6 +2080,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "dpp") == 0) { g_opt_dpp = value; return PICHA_OK; }
     if (strcmp(key, "sym") == 0) { g_opt_sym = value; return PICHA_OK; }
     if (strcmp(key, "rows") == 0) { g_opt_rows = value; return PICHA_OK; }
+    if (strcmp(key, "run") == 0) { g_opt_run = value; return PICHA_OK; }
     if (strcmp(key, "fuse") == 0) { g_opt_fuse = value; return PICHA_OK; }
     if (strcmp(key, "cc_mode") == 0) { g_opt_cc_mode = value; return PICHA_OK; }
     if (strcmp(key, "block_waves") == 0) { g_opt_block_waves = value; return PICHA_OK; }
@@ -1788,6 +2109,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "dpp") == 0) return g_opt_dpp;
     if (strcmp(key, "sym") == 0) return g_opt_sym;
     if (strcmp(key, "rows") == 0) return g_opt_rows;
+    if (strcmp(key, "run") == 0) return g_opt_run;
     if (strcmp(key, "fuse") == 0) return g_opt_fuse;
     if (strcmp(key, "cc_mode") == 0) return g_opt_cc_mode;
     if (strcmp(key, "block_waves") == 0) return g_opt_block_waves;

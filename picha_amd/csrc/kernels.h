@@ -220,6 +220,51 @@ int rows_window_align(int variant);   // window starts are multiples of this man
 bool rows_kernel_supported(int variant, int per_lane, int step, int taps);
 hipError_t launch_resize_rows_kernel(int variant, const RowsParams &p, hipStream_t s, const char **kernel_name);
 
+// ---- resize: run kernel (kernels_run.hip, r03): periodic tap tables, a lane resamples a run of consecutive outputs ----------
+struct RunParams {
+    const uint8_t *src;
+    uint8_t *dst;
+    long long src_pitch, dst_pitch;
+    const void *const *src_tab;
+    void *const *dst_tab;
+    int src_stride, dst_stride;
+    int src_w, src_h, dst_w, dst_h;
+    unsigned src_bytes, dst_bytes;
+    int n_images;
+    // x axis: the table repeats every `period` outputs / `period_px` source pixels; a lane owns x_per_lane (a multiple of the
+    // period) consecutive outputs; output x's window of x_taps pixels starts at x_base + (x / period) * period_px +
+    // ((x % period) * period_px) / period; x_canon = the period's weights [period][x_taps] in the kernel's flavour (plain,
+    // 1/max folded for fma, or scaled by 2^22 where the format unpacks through the denormal form)
+    int period, period_px, x_taps, x_per_lane, x_base, x_groups;
+    const float *x_canon;
+    int fma;
+    const int32_t *yrow_rec, *yrow_range;  // the accumulator kernel's per-source-row records
+    int nacc;
+    int rows_per_chunk, n_chunks;
+    int block_waves;  // waves per workgroup (1..4): adjacent column strips of the same rows
+    WorkList work;
+    int *resident_query;
+    // columns outside [cx0, cx1) have windows that an image edge clips (other weights): resize_edges_kernel recomputes them
+    // from the generic tables below after the march
+    int cx0, cx1;
+    // ... reading the source pixels from a stash the march writes: per (image, side, source row) the stash_words raw dwords of the
+    // lane that holds the side's columns; that lane's window starts stash_org[side] bytes into the row (a multiple of 4)
+    uint32_t *stash;       // [n_images][2][src_h][stash_words]; nullptr: no edge columns
+    int stash_words, stash_img0;
+    int stash_org[2];
+    int edge_rows;  // output rows per wave of that kernel (<= 64; its tables and horizontal sums must fit 8 KB of LDS: kernels_run.hip)
+    const int32_t *x_left, *x_count;
+    const float *x_weight;  // [dst_w][x_wtaps], reference weights
+    int x_wtaps;
+    const int32_t *y_count, *y_eff;
+    const float *y_weight;  // [dst_h][y_taps]
+    int y_taps;
+};
+bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc);
+hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s, const char **kernel_name);
+hipError_t launch_resize_edges_kernel(int pixel, const RunParams &p, hipStream_t s);  // after the run kernel, same stream: the columns outside [cx0, cx1)
+int run_kernel_resident_blocks(int pixel, const RunParams &p);
+
 // ---- Image helpers on device images (lib/image.js:57-73) -------------------------------------------
 struct CompareParams {
     const void *const *a_tab;  // per-image row-0 pointers (device arrays)

@@ -30,6 +30,46 @@ PICHA_DECL_STREAM(4) PICHA_DECL_STREAM(5) PICHA_DECL_STREAM(6) PICHA_DECL_STREAM
 PICHA_DECL_SYM(0) PICHA_DECL_SYM(1) PICHA_DECL_SYM(2) PICHA_DECL_SYM(3)
 PICHA_DECL_SYM(4) PICHA_DECL_SYM(5) PICHA_DECL_SYM(6) PICHA_DECL_SYM(7)
 #undef PICHA_DECL_SYM
+// defined in kernels_run.hip, one translation unit per pixel format
+#define PICHA_DECL_RUN(N)                                                                \
+    bool run_supported_pixel##N(int q, int px, int tx, int per_lane, int nacc);           \
+    hipError_t launch_run_pixel##N(const RunParams &p, hipStream_t s, const char **name); \
+    hipError_t launch_edges_pixel##N(const RunParams &p, hipStream_t s);
+PICHA_DECL_RUN(0) PICHA_DECL_RUN(1) PICHA_DECL_RUN(2) PICHA_DECL_RUN(3)
+PICHA_DECL_RUN(4) PICHA_DECL_RUN(5) PICHA_DECL_RUN(6) PICHA_DECL_RUN(7)
+#undef PICHA_DECL_RUN
+bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return run_supported_pixel##N(period, period_px, taps, per_lane, nacc);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return false;
+}
+hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s, const char **name) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return launch_run_pixel##N(p, s, name);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return hipErrorInvalidValue;
+}
+hipError_t launch_resize_edges_kernel(int pixel, const RunParams &p, hipStream_t s) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return launch_edges_pixel##N(p, s);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return hipErrorInvalidValue;
+}
+int run_kernel_resident_blocks(int pixel, const RunParams &p) {
+    RunParams q = p;
+    int n = 0;
+    q.resident_query = &n;
+    if (launch_resize_run_kernel(pixel, q, nullptr, nullptr) != hipSuccess) return 0;
+    return n;
+}
+
 bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int xch) {
     switch (pixel) {
 #define PICHA_CASE(N) case N: return sym_supported_pixel##N(per_lane, sx, tx, sy, ty, xch);

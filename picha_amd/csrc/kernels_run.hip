@@ -1,0 +1,443 @@
+// kernels_run.hip — downscale kernel for PERIODIC tap tables with long windows ("run" kernel, r03): a lane owns a run of P
+// consecutive outputs of one row and resamples them from one contiguous window of the source row held in registers.
+//
+// Where it applies: the scale src/dst is a ratio PX/Q of small integers (7.5 = 15/2: a 4K frame to 512 columns), so that
+// the reference's tap table (src/resize.cc:19-50) repeats every Q outputs — output x + Q has the weights of output x, bit
+// for bit, and its window starts PX source pixels later — for every output whose window does not hang over an image edge.
+// Then
+//   * the weights are WAVE-UNIFORM: Q x TX registers for the whole wave instead of P x TX lane-resident ones (the
+//     accumulator kernel needs 21-32 per output), which is what makes runs of 4-8 outputs per lane affordable;
+//   * a lane loads and converts the union of its outputs' windows ONCE per row: floor((P-1) PX / Q) + TX pixels for P
+//     outputs — at 7.5x / 21 taps 10.8 pixels per output for P = 4 against 21-24 for the one-output accumulator kernel
+//     and 15 + LDS traffic for the row-staged kernel (kernels_rows.hip), whose 8-pixel window alignment also rounds 21
+//     taps up to 32 multiply-adds;
+//   * no LDS, no barrier; the vertical part is the accumulator kernel's (per-source-row records, NACC pending output rows
+//     in registers), so every sum adds the reference's products in the reference's order: bit-exact in the reference flavour
+//     (src/resize.cc:110-117, 125-129).
+// The few columns whose windows are clipped by an image edge (renormalised weights: 4 of 512 for cfg3b) are left out by the
+// march (masked stores) and computed afterwards by the wave that holds them, one lane per output PIXEL of the chunk: the
+// reference's double sum straight from the source with that column's own weights (edge_pass below).  (A separate kernel for
+// them — one lane per pixel, lanes along y — took 0.17 ms on cfg3b against 0.62 for the march: every lane of a load touched
+// another cache line and re-fetched the lines of the rows its neighbours had just used.)
+#define PICHA_SPAN_ONLY 1
+#include "kernels_impl.inc"
+#ifndef PICHA_RUN_NB
+#define PICHA_RUN_NB 3
+#endif
+
+namespace picha_hip {
+namespace {
+
+// first pixel of output o's window relative to the window of output 0 of the same lane
+constexpr int run_off(int Q, int PX, int o) { return (o / Q) * PX + ((o % Q) * PX) / Q; }
+
+template <int CH, bool S16, int Q, int PX, int TX, int P> struct RunCfg {
+    static constexpr int BPS = Sample<S16>::kBytes;
+    static constexpr int BPP = CH * BPS;
+    static constexpr int SPAN = run_off(Q, PX, P - 1) + TX;  // source pixels a lane reads per row
+    static constexpr bool WORDS = (BPP % 4 == 0);
+    static constexpr bool BYTESPAN = !WORDS;
+    static constexpr bool BROT = !WORDS;                     // sub-dword pixels: aligned dwords + v_alignbyte by the lane's byte phase
+    static constexpr int NWIN = (SPAN * BPP + 3) / 4;
+    static constexpr int NW = WORDS ? SPAN * BPP / 4 : NWIN + 1;
+};
+
+// window of one edge-column pixel: TXE >= the table's taps, whole dwords
+template <int CH, bool S16, int TXE> struct EdgeCfg {
+    static constexpr int BPS = Sample<S16>::kBytes;
+    static constexpr int BPP = CH * BPS;
+    static constexpr int SPAN = TXE;
+    static constexpr bool WORDS = (BPP % 4 == 0);
+    static constexpr bool BYTESPAN = !WORDS;
+    static constexpr bool BROT = !WORDS;
+    static constexpr int NWIN = (SPAN * BPP + 3) / 4;
+    static constexpr int NW = WORDS ? SPAN * BPP / 4 : NWIN + 1;
+};
+
+// Edge columns [xa0, xa0 + na) of one side of one image for the output rows [y0, y1), by one wave; the reference's double sum
+// (src/resize.cc:110-117 into a zeroed row, :125-129 over the window's rows; the y tables of this kernel have no ring aliasing,
+// so those are rows left .. left + count - 1) with the columns' own weights from the generic tables, reference arithmetic in
+// both numerics flavours.  The source pixels come from the STASH the march wrote: per (image, side, source row) the NRAW raw
+// dwords of the lane that holds the side's edge columns (stash_rs describes this image-side's rows, st_stride bytes apart; the
+// side's lane window starts st_org bytes into the image row, a multiple of 4, possibly negative).  Through kEdgeFloats floats of LDS:
+//   0  the columns' x weights and the block's y weights go to LDS (coalesced loads);
+//   A  one lane per (edge column, SOURCE row of the block): the horizontal sum; lanes read consecutive stash rows;
+//   B  one lane per (edge column, output row): the vertical sum over the stored horizontal sums, pack, store.
+// Why a stash: fetched from the image itself every window costs a 128-byte line of HBM for 30 bytes of payload, once more than
+// the march already paid (141-283 MB for cfg3b: 0.03-0.07 ms, alone or as an epilogue of the march's waves, whatever the form
+// of the loop — r03, profiles/r03_ab_run_kernel.txt); the march has those bytes in registers.
+constexpr int kEdgeFloats = 2048;
+template <int CH, bool S16, int TXE>
+__device__ __forceinline__ void edge_pass(const RunParams &p, __amdgpu_buffer_rsrc_t stash_rs, int st_stride, int st_org, __amdgpu_buffer_rsrc_t dst_rs,
+                                          int lane, float *lds, int xa0, int na, int y0, int y1) {
+    using E = EdgeCfg<CH, S16, TXE>;
+    constexpr bool SC = exact_unpack_scaled(CH, S16);  // such formats unpack through the denormal form: weights times 2^22 (exact)
+    const_i32_ptr xl = (const_i32_ptr)(p.x_left);
+    const_i32_ptr yrange = (const_i32_ptr)(p.yrow_range);
+    const int ncol = na;
+    float *lds_wx = lds;                       // [ncol][TXE]
+    for (int ya = y0; ya < y1; ya += p.edge_rows) {
+        const int yb = min(y1, ya + p.edge_rows), rows = yb - ya;
+        float *lds_wy = lds_wx + ncol * TXE;   // [rows][y_taps]
+        float *lds_h = lds_wy + rows * p.y_taps;  // [ncol][nsr][CH]
+        // source rows of the block (the march's table: first row needed by ya or any later row, last row needed up to yb - 1)
+        const int ra = yrange[2 * ya], rb = yrange[2 * (yb - 1) + 1];
+        const int nsr = rb - ra + 1;  // ncol * nsr * CH floats from lds_h on: host-sized blocks (capi.cpp, run_group)
+        // ---- 0: weights to LDS ----
+        for (int i = lane; i < ncol * TXE; i += kWave) {
+            const int c = i / TXE, j = i % TXE;
+            const int x = xa0 + c;
+            const float w = p.x_weight[(size_t)x * p.x_wtaps + min(j, p.x_wtaps - 1)];
+            lds_wx[i] = j < p.x_count[x] ? (SC ? w * kWeightScale : w) : 0.0f;
+        }
+#pragma unroll 8
+        for (int i = lane; i < rows * p.y_taps; i += kWave) lds_wy[i] = p.y_weight[(size_t)ya * p.y_taps + i];
+        const int yl = min(ya + lane, yb - 1);     // phase B's row of this lane (block rows <= 64)
+        const int ny_l = p.y_count[yl], left_l = p.y_eff[(size_t)yl * p.y_taps];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- A: horizontal sums, one column after the other; G groups of 64 source rows (one window per lane) in flight ----
+        // (no run-time integer division anywhere in this kernel: its expansion uses v_fmac, which the ISA test reserves for the fma flavour)
+        constexpr int G = E::NW <= 12 ? 4 : 2;
+        for (int c = 0; c < ncol; ++c) {
+            const int32_t bo = xl[xa0 + c] * E::BPP - st_org;   // window start inside the stash row: >= 0 (host-checked containment)
+            const uint32_t phase = uint32_t(bo) & 3u;
+            for (int s0 = 0; s0 < nsr; s0 += G * kWave) {
+                uint32_t raw[G][E::NW];
+#pragma unroll
+                for (int g = 0; g < G; ++g)
+                    load_span<E, false>(stash_rs, (ra + min(s0 + g * kWave + lane, nsr - 1)) * st_stride + (bo & ~3), raw[g]);
+#pragma unroll
+                for (int g = 0; g < G; ++g) {
+                    if (s0 + g * kWave < nsr) {  // wave-uniform
+                        const int sr = s0 + g * kWave + lane;
+                        uint32_t win[E::BROT ? E::NWIN : 1];
+                        if constexpr (E::BROT) rotate_span<E>(raw[g], phase, win);
+                        float h[CH];
+#pragma unroll
+                        for (int t = 0; t < TXE; ++t) {
+                            float u[CH];
+                            if constexpr (E::BROT) unpack_span_px<E, CH, S16, false>(win, t, u);
+                            else unpack_span_px<E, CH, S16, false>(raw[g], t, u);
+                            const float w = lds_wx[c * TXE + t];  // every lane the same address
+#pragma unroll
+                            for (int ch = 0; ch < CH; ++ch) h[ch] = t == 0 ? w * u[ch] : h[ch] + w * u[ch];
+                        }
+                        if (sr < nsr) {
+#pragma unroll
+                            for (int ch = 0; ch < CH; ++ch) lds_h[(c * nsr + sr) * CH + ch] = h[ch];
+                        }
+                    }
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- B: vertical sums; lane = output row, one column after the other ----
+        int ny_max = ny_l;  // wave maximum
+#pragma unroll
+        for (int m = 1; m < kWave; m <<= 1) ny_max = max(ny_max, __shfl_xor(ny_max, m));
+        ny_max = __builtin_amdgcn_readfirstlane(ny_max);
+        for (int c = 0; c < ncol; ++c) {
+            const int x = xa0 + c;
+            float acc[CH];
+#pragma unroll
+            for (int ch = 0; ch < CH; ++ch) acc[ch] = 0.0f;
+            for (int j = 0; j < ny_max; ++j) {
+                const float wj = j < ny_l ? lds_wy[(yl - ya) * p.y_taps + j] : 0.0f;
+                const int sr = min(max(left_l + min(j, ny_l - 1) - ra, 0), nsr - 1);
+#pragma unroll
+                for (int ch = 0; ch < CH; ++ch) acc[ch] = acc[ch] + wj * lds_h[(c * nsr + sr) * CH + ch];
+            }
+            if (ya + lane < yb) {
+                uint32_t pw[2];
+                pack_px_words<CH, S16, false>(acc, pw);
+                store_px_words<CH, S16>(dst_rs, uint32_t(yl * p.dst_stride + x * E::BPP), pw);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// One wave per (block of p.edge_rows output rows, side of the image, image): launched after the march on the same stream, it
+// overwrites what the march stored in those columns with the canonical weights.  (As an epilogue of the march's waves the pass
+// cost 25 VGPRs on top of the march's and 5-12 % of its time.)
+template <int CH, bool S16, int TXE>
+__global__ __launch_bounds__(64) void resize_edges_kernel(RunParams p) {
+    extern __shared__ __attribute__((aligned(16))) float edge_lds[];
+    const int lane = threadIdx.x;
+    const int img = blockIdx.z, side = blockIdx.y;
+    const int y0 = blockIdx.x * p.edge_rows, y1 = min(p.dst_h, y0 + p.edge_rows);
+    const int xa0 = side == 0 ? 0 : p.cx1;
+    const int na = side == 0 ? p.cx0 : p.dst_w - p.cx1;
+    if (y0 >= y1 || na <= 0) return;
+    uint8_t *dbase = uniform_ptr(p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch);
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
+    const unsigned st_stride = unsigned(p.stash_words) * 4u, st_bytes = st_stride * unsigned(p.src_h);
+    const __amdgpu_buffer_rsrc_t stash_rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<uint8_t *>(p.stash) + (size_t)((p.stash_img0 + img) * 2 + side) * st_bytes, 0, st_bytes, 0x00020000);
+    edge_pass<CH, S16, TXE>(p, stash_rs, int(st_stride), p.stash_org[side], dst_rs, lane, edge_lds, xa0, na, y0, y1);
+}
+
+template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC, bool FMA>
+__global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
+    using C = RunCfg<CH, S16, Q, PX, TX, P>;
+    static_assert(P % Q == 0, "a lane owns whole periods");
+    constexpr int NRAW = C::NW;
+    constexpr int NB = NRAW <= 16 ? PICHA_RUN_NB : 2;  // row buffers
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+    auto run_item = [&](int bx, int y0, int y1, int img) __attribute__((always_inline)) {
+    const int grp0 = (bx * bw + wave) * kWave;
+    if (grp0 * P >= p.dst_w) return;
+    const int x0 = (grp0 + lane) * P;
+
+    const uint8_t *sbase = uniform_ptr(p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch);
+    uint8_t *dbase = uniform_ptr(p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch);
+    const int sadj = C::BROT ? int(reinterpret_cast<uintptr_t>(sbase) & 3u) : 0;
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(sbase) - sadj, 0, C::WORDS ? p.src_bytes : ((p.src_bytes + sadj + 3u) & ~3u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
+    if (y0 >= y1) return;
+
+    // canonical weights of the Q outputs of a period: scalar loads, then VGPRs (an SGPR operand halves the VALU rate)
+    // (all scalar loads first, as wide as they merge, then the moves: one load and one wait per weight cost ~10 us per wave)
+    const_i32_ptr xc = (const_i32_ptr)(p.x_canon);
+    int32_t wbits[Q * TX];
+#pragma unroll
+    for (int j = 0; j < Q * TX; ++j) wbits[j] = xc[j];
+    float wx[Q][TX];
+#pragma unroll
+    for (int q = 0; q < Q; ++q)
+#pragma unroll
+        for (int j = 0; j < TX; ++j) asm("v_mov_b32 %0, %1" : "=v"(wx[q][j]) : "s"(wbits[q * TX + j]));
+    // the lane's window starts at x_base + PX * (x0 / Q): x0 is a multiple of P, P of Q
+    const int32_t lane_off = (p.x_base + (grp0 + lane) * ((P / Q) * PX)) * C::BPP + sadj;
+    // a window that starts before the image (left-most lane) must not wrap a merged load in row 0
+    const bool careful = __any(lane_off < 0);
+
+    const_i32_ptr yrange = (const_i32_ptr)(p.yrow_range);
+    const_i32_ptr yrec = (const_i32_ptr)(p.yrow_rec);
+    const int r0 = yrange[2 * y0];
+    const int r1 = yrange[2 * (y1 - 1) + 1];
+
+    float acc[NACC][P][CH];
+#pragma unroll
+    for (int a = 0; a < NACC; ++a)
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[a][q][c] = 0.0f;
+
+    // NB row buffers in registers, NB - 1 rows in flight.  Only the loads BEFORE the loop can meet row 0 with a negative offset
+    // (clamped dword by dword, load_span<.., true>); the loop's own loads are rows >= 1, where a negative lane offset lands in
+    // the previous row: one merged, branch-free load sequence — a second load path inside the loop made the compiler wait for
+    // the prefetch it had just issued.
+    uint32_t raw[NB][NRAW];
+#pragma unroll
+    for (int k = 0; k < NB - 1; ++k) {
+        const int row = min(r0 + k, r1);
+        const int32_t off = row * p.src_stride + lane_off;
+        if (careful && row <= 0) load_span<C, true>(src_rs, off, raw[k]);
+        else load_span<C, false>(src_rs, off, raw[k]);
+    }
+
+    // The lanes that hold the image's first / last columns keep their raw dwords of every row for resize_edges_kernel: into a
+    // wave-private LDS buffer of 64 rows per side, flushed to the global stash with one coalesced store sequence per 64 rows.
+    // (Stored straight to memory, one lane and four store instructions per row, the march ran 10-17 % longer: on gfx9 stores
+    // count in vmcnt like loads, so every counted wait for a row's pixels also waited for the stash stores issued before it.)
+    extern __shared__ __attribute__((aligned(16))) uint32_t stash_lds[];   // [waves][2 sides][64 rows][NRAW]
+    const int g_last = (p.dst_w - 1) / P;
+    const int st_side_lane = p.stash == nullptr ? -1 : (grp0 + lane == 0) ? 0 : (grp0 + lane == g_last) ? 1 : -1;
+    const bool st_has0 = __any(st_side_lane == 0), st_has1 = __any(st_side_lane == 1);
+    const bool st_wave = st_has0 || st_has1;
+    constexpr int NRP = (NRAW + 3) / 4 * 4;   // LDS pitch of a stash row: 16-byte stores
+    uint32_t *st_buf = stash_lds + wave * (2 * kWave * NRP);
+    const unsigned st_stride = unsigned(p.stash_words) * 4u, st_bytes = st_stride * unsigned(p.src_h);
+    const __amdgpu_buffer_rsrc_t stash_rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<uint8_t *>(p.stash) + (size_t)(p.stash_img0 + img) * 2 * st_bytes, 0, p.stash ? 2 * st_bytes : 0, 0x00020000);
+    auto stash_row = [&](uint32_t (&cur)[NRAW], int row) __attribute__((always_inline)) {
+        const int slot = (row - r0) & (kWave - 1);
+        if (st_side_lane >= 0) {
+            u32x4 *d4 = reinterpret_cast<u32x4 *>(st_buf + (st_side_lane * kWave + slot) * NRP);
+#pragma unroll
+            for (int k4 = 0; k4 < NRP / 4; ++k4) {
+                u32x4 v = {cur[4 * k4], 4 * k4 + 1 < NRAW ? cur[4 * k4 + 1] : 0u, 4 * k4 + 2 < NRAW ? cur[4 * k4 + 2] : 0u, 4 * k4 + 3 < NRAW ? cur[4 * k4 + 3] : 0u};
+                d4[k4] = v;
+            }
+        }
+        if (slot == kWave - 1 || row == r1) {  // wave-uniform: flush rows [row - slot, row]
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                if (side == 0 ? st_has0 : st_has1) {
+                    if (lane <= slot) {
+                        uint32_t t[NRAW];
+#pragma unroll
+                        for (int k = 0; k < NRAW; ++k) t[k] = st_buf[(side * kWave + lane) * NRP + k];
+                        store_dwords<NRAW>(stash_rs, uint32_t(side) * st_bytes + uint32_t(row - slot + lane) * st_stride, t);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+    auto process_row = [&](uint32_t (&cur)[NRAW], int row) __attribute__((always_inline)) {
+        if (st_wave && row <= r1) stash_row(cur, row);  // wave-uniform
+        int rec[2 * NACC];
+#pragma unroll
+        for (int t = 0; t < 2 * NACC; ++t) rec[t] = yrec[(size_t)row * (2 * NACC) + t];
+        // ---- horizontal pass (src/resize.cc:110-117): every window pixel converted once, used by all outputs it is a tap of ----
+        float h[P][CH];
+        uint32_t win[C::BROT ? C::NWIN : 1];
+        if constexpr (C::BROT) rotate_span<C>(cur, uint32_t(min(row, r1) * p.src_stride + lane_off) & 3u, win);
+#pragma unroll
+        for (int q = 0; q < C::SPAN; ++q) {
+            float u[CH];
+            if constexpr (C::BROT) unpack_span_px<C, CH, S16, FMA>(win, q, u);
+            else unpack_span_px<C, CH, S16, FMA>(cur, q, u);
+#pragma unroll
+            for (int o = 0; o < P; ++o) {
+                const int j = q - run_off(Q, PX, o);  // tap index of window pixel q for output o
+                if (j >= 0 && j < TX) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        if (j == 0) h[o][c] = wx[o % Q][0] * u[c];
+                        else if constexpr (FMA) h[o][c] = __builtin_fmaf(wx[o % Q][j], u[c], h[o][c]);
+                        else h[o][c] = h[o][c] + wx[o % Q][j] * u[c];
+                    }
+                }
+            }
+        }
+        // ---- fold the row into the pending output rows (src/resize.cc:125-129) ----
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            float w;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(w) : "s"(rec[a]));
+#pragma unroll
+            for (int o = 0; o < P; ++o)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    if constexpr (FMA) acc[a][o][c] = __builtin_fmaf(w, h[o][c], acc[a][o][c]);
+                    else acc[a][o][c] = acc[a][o][c] + w * h[o][c];
+                }
+        }
+        // ---- output rows whose window ends with this source row: pack, store (whole dwords: host-checked alignment), clear ----
+#pragma unroll
+        for (int a = 0; a < NACC; ++a) {
+            const int y = rec[NACC + a];
+            if (y >= 0) {  // wave-uniform
+                if (y >= y0 && y < y1) store_lane_outputs<C, CH, S16, P, FMA>(acc[a], dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
+#pragma unroll
+                for (int o = 0; o < P; ++o)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) acc[a][o][c] = 0.0f;
+            }
+        }
+    };
+
+    // rows past r1 inside the last group of NB are ghosts: they re-read row r1 and use the records of rows > r1, in which every
+    // output of this chunk has weight 0 and none of them completes
+    for (int r = r0; r <= r1; r += NB) {
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            load_span<C, false>(src_rs, max(1, min(r + k + NB - 1, r1)) * p.src_stride + lane_off, raw[(k + NB - 1) % NB]);
+            process_row(raw[k], r + k);
+        }
+    }
+    };  // run_item
+    run_work_items(p.work, [&](int &bx, int &y0, int &y1, int &img) __attribute__((always_inline)) {
+        bx = blockIdx.x; y0 = blockIdx.y * p.rows_per_chunk; y1 = min(p.dst_h, y0 + p.rows_per_chunk); img = blockIdx.z;
+    }, run_item);
+}
+
+template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC>
+hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
+    const void *k = p.fma ? reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true>)
+                          : reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false>);
+    const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 4;
+    const size_t lds = p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, Q, PX, TX, P>::NW + 3) / 4 * 4) : 0;   // the stash staging of the edge lanes
+    if (p.resident_query) {
+        int per_cu = 0, dev = 0, cus = 0;
+        hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * bw, lds);
+        if (e == hipSuccess) e = hipGetDevice(&dev);
+        if (e == hipSuccess) e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        *p.resident_query = e == hipSuccess ? per_cu * cus : 0;
+        return e;
+    }
+    dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
+    if (p.work.items) grid = dim3(p.work.queue ? (unsigned)p.n_chunks : 8u * (unsigned)p.work.items_per_xcd, 1, 1);
+    if (p.fma) resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true><<<grid, 64 * bw, lds, s>>>(p);
+    else resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false><<<grid, 64 * bw, lds, s>>>(p);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_run<ch%d,%s,Q%d,PX%d,TX%d,P%d,NACC%d,%s,bw%d%s>", CH, S16 ? "u16" : "u8", Q, PX, TX, P, NACC,
+             p.fma ? "fma" : "exact", bw, work_suffix(p.work));
+    if (name) *name = g_kernel_name;
+    return hipGetLastError();
+}
+
+// Instantiations per pixel format: X(Q, PX, TX, P) — period in outputs, period in source pixels, taps, outputs per lane; each
+// with 4 and 6 pending output rows.  7.5x (15/2: a 4K frame to 512 columns): 21 taps with picha's default filter scale, 31
+// (30 + the half pixel) at filter scale 1, for every filter but box / triangle.  Survey over formats (r03, 128 x 4K -> 512x288,
+// profiles/r03_survey_run_kernel.txt): grey 31 taps -13 % against the row-staged kernel (fma -20 %), greya 31 taps -35 % (two
+// outputs per lane), grey 21 taps -11 % on 256 images and a tie on 128; rgb / rgba / r16 were ties (-3 .. +4 %) and are not
+// instantiated (rgba at 31 taps does not fit the edge kernel's LDS block either).
+#define PICHA_RUN_LIST_0(X) /* rgb */
+#define PICHA_RUN_LIST_1(X) /* rgba */
+#define PICHA_RUN_LIST_2(X) /* grey */ X(2, 15, 21, 2) X(2, 15, 21, 4) X(2, 15, 21, 8) X(2, 15, 31, 2) X(2, 15, 31, 4)
+#define PICHA_RUN_LIST_3(X) /* greya */ X(2, 15, 21, 2) X(2, 15, 31, 2) X(2, 15, 31, 4)
+#define PICHA_RUN_LIST_4(X) /* r16 */
+#define PICHA_RUN_LIST_5(X) /* r16g16 */
+#define PICHA_RUN_LIST_6(X) /* r16g16b16 */
+#define PICHA_RUN_LIST_7(X) /* r16g16b16a16 */
+
+}  // namespace
+
+#ifndef PICHA_RUN_PIXEL
+#error "compile with -DPICHA_RUN_PIXEL=0..7"
+#endif
+#define PICHA_CAT2(a, b) a##b
+#define PICHA_CAT(a, b) PICHA_CAT2(a, b)
+#define PICHA_RUN_LIST PICHA_CAT(PICHA_RUN_LIST_, PICHA_RUN_PIXEL)
+
+bool PICHA_CAT(run_supported_pixel, PICHA_RUN_PIXEL)(int q, int px, int tx, int per_lane, int nacc) {
+    if (nacc != 4 && nacc != 6) return false;
+#define X(Q, PX, TX, P) if (q == Q && px == PX && tx == TX && per_lane == P) return true;
+    PICHA_RUN_LIST(X)
+#undef X
+    return false;
+}
+
+hipError_t PICHA_CAT(launch_run_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipStream_t s, const char **name) {
+    [[maybe_unused]] constexpr int CH = pixel_channels(PICHA_RUN_PIXEL);
+    [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
+#define X(Q, PX, TX, P)                                                                                   \
+    if (p.period == Q && p.period_px == PX && p.x_taps == TX && p.x_per_lane == P) {                      \
+        if (p.nacc == 4) return launch_run_t<CH, S16, Q, PX, TX, P, 4>(p, s, name);                       \
+        if (p.nacc == 6) return launch_run_t<CH, S16, Q, PX, TX, P, 6>(p, s, name);                       \
+    }
+    PICHA_RUN_LIST(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+hipError_t PICHA_CAT(launch_edges_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipStream_t s) {
+    [[maybe_unused]] constexpr int CH = pixel_channels(PICHA_RUN_PIXEL);
+    [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
+    if (!p.stash) return hipSuccess;
+    dim3 grid((p.dst_h + p.edge_rows - 1) / p.edge_rows, 2, p.n_images);
+    const size_t lds = sizeof(float) * kEdgeFloats;
+    const int txe = (p.x_taps + 3) / 4 * 4;
+#define X(Q, PX, TX, P) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
+    PICHA_RUN_LIST(X)
+#undef X
+    return hipErrorInvalidValue;
+}
+
+}  // namespace picha_hip

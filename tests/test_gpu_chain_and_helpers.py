@@ -209,6 +209,106 @@ def test_row_staged_downscale_kernel_matches_oracle(case):
             N.check(N.lib().picha_hip_set_option(k, 0))
 
 
+RUN_CASES = [
+    ("grey", (960, 270), (128, 64), "lanczos", 1.0, 31),      # cfg3b's structure: 7.5x in x (period 2 / 15 pixels), 4.2x in y
+    ("grey", (960, 540), (128, 72), "cubic", 0.70, 21),       # 7.5x both ways, picha's default options (21 taps)
+    ("grey", (1920, 90), (256, 37), "mitchel", 1.0, 31),      # two waves per row (four outputs per lane), odd output height
+    ("grey", (975, 300), (130, 40), "catmulrom", 0.70, 21),   # the last lane's run hangs over the row end (130 = 32 * 4 + 2)
+    ("greya", (960, 270), (128, 64), "lanczos", 1.0, 31),     # two-byte pixels: two (default) or four outputs per lane
+    ("greya", (1950, 150), (260, 20), "cubic", 0.70, 21),     # five row pieces of 64 lanes, the last one ragged
+]
+RUN_PER_LANE = {("grey", 21): (0, 2, 4, 8), ("grey", 31): (0, 2, 4), ("greya", 21): (0, 2), ("greya", 31): (0, 2, 4)}
+
+
+@pytest.mark.parametrize("case", RUN_CASES, ids=lambda c: "%s-%dx%d-%s" % (c[0], c[1][0], c[1][1], c[3]))
+def test_run_kernel_matches_oracle(case):
+    """r03: the run kernel (kernels_run.hip: periodic tap tables, a lane resamples a run of 2 / 4 / 8 consecutive outputs with
+    wave-uniform weights; the columns whose windows an image edge clips are recomputed by resize_edges_kernel from the stash of
+    raw pixels the march leaves) against the oracle: every outputs-per-lane form, row chunkings, the three launch forms, padded
+    strides, a device batch, and the fma flavour; run = 2 gives the kernel it replaces, which must agree byte for byte."""
+    from picha_amd.device import DeviceBatch, resize_batch
+    import torch
+    pixel, (sw, sh), (dw, dh), filt, fscale, taps = case
+    ch = N.PIXEL_CHANNELS[pixel]
+    rng = np.random.default_rng(sw + 17 * dh)
+    img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 4, 8])))
+    want = oracle_resize(img, dw, dh, filt, fscale)
+    opts = {"width": dw, "height": dh, "filter": filt, "filterScale": fscale}
+    keys = (b"run", b"per_lane", b"row_chunks", b"work", b"numerics", b"block_waves")
+    try:
+        N.check(N.lib().picha_hip_set_option(b"run", 1))
+        for per_lane in RUN_PER_LANE[(pixel, taps)]:
+            for chunks, work in ((0, 0), (1, 3), (3, 1), (2, 2)):
+                N.check(N.lib().picha_hip_set_option(b"per_lane", per_lane))
+                N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
+                N.check(N.lib().picha_hip_set_option(b"work", work))
+                got = picha.resizeSync(img, opts)
+                name = N.lib().picha_hip_last_kernel().decode()
+                assert name.startswith("resize_run<ch%d,u8,Q2,PX15,TX%d,P%d," % (ch, taps, per_lane or (4 if ch == 1 else 2))), name
+                assert "+ resize_edges<" in name, name
+                assert max_code_diff(got, want) == 0, (case, per_lane, chunks, work, name)
+        for k in keys[1:]:
+            N.check(N.lib().picha_hip_set_option(k, 0))
+        N.check(N.lib().picha_hip_set_option(b"block_waves", 1))
+        got = picha.resizeSync(img, opts)
+        assert ",bw1" in N.lib().picha_hip_last_kernel().decode() and max_code_diff(got, want) == 0
+        N.check(N.lib().picha_hip_set_option(b"block_waves", 0))
+        N.check(N.lib().picha_hip_set_option(b"run", 2))
+        got = picha.resizeSync(img, opts)
+        assert not N.lib().picha_hip_last_kernel().decode().startswith("resize_run<")
+        assert max_code_diff(got, want) == 0
+        N.check(N.lib().picha_hip_set_option(b"run", 1))
+        N.check(N.lib().picha_hip_set_option(b"numerics", 1))
+        got = picha.resizeSync(img, opts)
+        assert N.lib().picha_hip_last_kernel().decode().startswith("resize_run<") and max_code_diff(got, want) <= 1
+        N.check(N.lib().picha_hip_set_option(b"numerics", 0))
+        # a device batch
+        n = 5
+        src = DeviceBatch(n, sw, sh, pixel).fill_random(3 + sw)
+        out = resize_batch(src, dw, dh, filter=filt, filter_scale=fscale)
+        torch.cuda.synchronize()
+        assert N.lib().picha_hip_last_kernel().decode().startswith("resize_run<")
+        for i in range(n):
+            exp = oracle_resize(src.image_host(i), dw, dh, filt, fscale)
+            assert np.array_equal(out.image_host(i).pixels(), exp.pixels()), (case, i)
+    finally:
+        for k in keys:
+            N.check(N.lib().picha_hip_set_option(k, 0))
+
+
+def test_run_kernel_is_the_planners_choice_only_where_it_was_measured_faster():
+    """Default options: long windows (>= 26 taps) of grey / greya at a periodic scale take the run kernel; 21-tap windows only
+    for large grey batches; other formats, non-periodic scales and a forced row-staged kernel never."""
+    from picha_amd.device import DeviceBatch, resize_batch
+    import torch
+    rng = np.random.default_rng(11)
+    last = lambda: N.lib().picha_hip_last_kernel().decode()
+    for pixel, (sw, sh), (dw, dh), o, expect in [
+        ("grey", (960, 270), (128, 64), {"filter": "lanczos"}, True),
+        ("greya", (960, 270), (128, 64), {"filter": "lanczos"}, True),
+        ("grey", (960, 540), (128, 72), {}, False),                       # 21 taps, one image
+        ("rgba", (960, 270), (128, 64), {"filter": "lanczos"}, False),
+        ("grey", (1000, 270), (128, 64), {"filter": "lanczos"}, False),    # 7.8125x: period 16
+    ]:
+        img = rand_image(rng, sw, sh, pixel)
+        got = picha.resizeSync(img, dict(o, width=dw, height=dh))
+        assert last().startswith("resize_run<") == expect, (pixel, sw, last())
+        assert max_code_diff(got, oracle_resize(img, dw, dh, o.get("filter", "cubic"), 1.0 if "filter" in o else 0.70)) == 0
+    src = DeviceBatch(192, 960, 540, "grey").fill_random(2)
+    out = resize_batch(src, 128, 72)
+    torch.cuda.synchronize()
+    assert last().startswith("resize_run<ch1,u8,Q2,PX15,TX21,P4,"), last()
+    for i in (0, 95, 191):
+        assert np.array_equal(out.image_host(i).pixels(), oracle_resize(src.image_host(i), 128, 72).pixels())
+    N.check(N.lib().picha_hip_set_option(b"rows", 1))
+    try:
+        img = rand_image(rng, 960, 270, "grey")
+        picha.resizeSync(img, {"width": 128, "height": 64, "filter": "lanczos"})
+        assert last().startswith("resize_rows<"), last()
+    finally:
+        N.check(N.lib().picha_hip_set_option(b"rows", 0))
+
+
 def test_convert_resize_chain_same_format_is_plain_resize_and_errors_match():
     rng = np.random.default_rng(5)
     img = rand_image(rng, 40, 30, "rgb")

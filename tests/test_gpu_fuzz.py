@@ -17,7 +17,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up", "run"):
         set_opt(k, 0)
 
 
@@ -114,6 +114,46 @@ def test_random_resizes_match_oracle(seed):
             seed, sw, sh, dw, dh, pixel, opts, path, numerics, name, img.stride, img.data.ctypes.data % 16, d)
         checked += 1
     assert checked > 40
+
+
+@pytest.mark.parametrize("seed", range(max(2, N_SEEDS // 3)))
+def test_random_half_integer_downscales_match_oracle(seed):
+    """r03: 7.5x in x (the run kernel's period 2 / 15 pixels) with random heights, strides, sub-views, filters and launch options;
+    grey and greya take the run kernel + edge kernel where an instantiation exists (21 / 31 taps), everything else falls through
+    to the other kernels — all of it against the oracle."""
+    rng = np.random.default_rng(BASE + 7000 + seed)
+    ran = 0
+    for _ in range(40):
+        dw = 2 * int(rng.integers(2, 200))
+        sw = dw * 15 // 2
+        dh = int(rng.integers(1, 60))
+        sh = dh * int(rng.integers(1, 9)) + int(rng.integers(1, 7))
+        pixel = str(rng.choice(["grey", "grey", "greya", "greya", "rgb", "r16"]))
+        img = rand_image(rng, sw + int(rng.integers(0, 2)) * 4, sh + int(rng.integers(0, 3)), pixel, pad=int(rng.choice([0, 0, 4, 8])),
+                         edge_values=bool(rng.integers(0, 4) == 0))
+        if img.width > sw or img.height > sh:
+            img = img.subView(img.width - sw, img.height - sh, sw, sh)
+        opts = {"width": dw, "height": dh}
+        filt, fscale = "cubic", 0.70
+        if rng.integers(0, 2):
+            filt = str(rng.choice(["lanczos", "mitchel", "catmulrom", "cubic", "triangle"]))
+            opts["filter"] = filt
+            fscale = 1.0
+        exp = oracle_resize(img, dw, dh, filt, fscale)
+        numerics = int(rng.integers(0, 4) == 0)
+        set_opt("numerics", numerics)
+        set_opt("run", int(rng.choice([1, 1, 0])))
+        set_opt("per_lane", int(rng.choice([0, 0, 2, 4, 8])))
+        set_opt("row_chunks", int(rng.choice([0, 0, 1, 2, 5])))
+        set_opt("work", int(rng.choice([0, 0, 1, 2, 3])))
+        set_opt("block_waves", int(rng.choice([0, 0, 1, 2, 4])))
+        got = picha_amd.resizeSync(img, opts)
+        name = N.lib().picha_hip_last_kernel().decode()
+        ran += name.startswith("resize_run<")
+        d = max_code_diff(got, exp)
+        assert d <= (1 if numerics else 0), "seed %d: %dx%d -> %dx%d %s opts %r numerics %d kernel %s stride %d offset %d: diff %d" % (
+            seed, sw, sh, dw, dh, pixel, opts, numerics, name, img.stride, img.data.ctypes.data % 16, d)
+    assert ran >= 5, ran
 
 
 def test_random_color_converts_match_oracle():
