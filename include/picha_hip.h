@@ -124,8 +124,9 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "path"       0 = auto, 1 = force the two-pass scratch kernels, 2 = force a fused kernel (error if
  *                none applies), 3 = the LDS-ring span kernel (never the streaming or accumulator kernels),
  *                4 = the accumulator kernel (error if the tap table is not representable), 5 = the row-staged
- *                LDS kernel (error if it does not apply).  Chained convert + resize calls honour it too: the
- *                fused convert+resize kernel is only taken for 0 and 5
+ *                LDS kernel (error if it does not apply), 6 = the run kernel (periodic tap tables; error if it does
+ *                not apply).  Chained convert + resize calls honour it too: the fused convert+resize kernel is only
+ *                taken for 0 and 5
  *   "acc"        accumulator kernel: 0 = auto, 1 = whenever representable, 2 = never
  *   "acc_p2"     accumulator kernel with two outputs per lane: 0 = auto (measured table), 1 = whenever a shape
  *                exists, 2 = never
@@ -149,6 +150,11 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "block_waves"  waves per workgroup of the symmetric-table kernel (1..4, 0 = auto)
  *   "sym_sync"   1 = one barrier per step keeps the waves of such a workgroup on the same source rows
  *   "rows"       row-staged LDS downscale kernel: 0 = auto, 1 = whenever it applies, 2 = never
+ *   "run"        run kernel (scale = a ratio of small integers, e.g. 7.5: a lane resamples a run of consecutive outputs
+ *                with wave-uniform weights; the edge columns come from a second small kernel): 0 = auto (grey / greya
+ *                with >= 26 taps, shorter grey windows for batches of >= 192 images), 1 = wherever an instantiation
+ *                exists, 2 = never.  "per_lane" (2, 4, 8), "row_chunks", "block_waves" and "work" (1, 2; default
+ *                plain grid) apply to it too
  *   "fuse"       picha_hip_convert_resize*: 0 = one fused kernel where it exists and was measured faster (default: every
  *                convert -> downscale pair of the row-staged kernel; resize -> convert for 16-bit and rgba sources), 1 = one
  *                kernel wherever an instantiation exists, 2 = always two kernels
@@ -174,6 +180,8 @@ long picha_hip_get_option(const char *key);
  *   "resize_acc<...>"        accumulator kernel ("P2": two outputs per lane, ",xch"; "S0": upscale shape, outputs share one
  *                            window; ",epilogue -> fmt": colour convert fused in at the store), "resize_acc_long<...>" (> 36 taps)
  *   "resize_rows<...>"       row-staged LDS kernel ("src chN -> chM": colour convert fused in)
+ *   "resize_run<...> + resize_edges<N columns>"   run kernel (Q outputs / PX source pixels per period, P outputs per lane)
+ *                            and the kernel that recomputes the N columns whose windows an image edge clips
  *   "resize_span<...>"       LDS-ring span kernel (upscales, ring-aliasing cases)
  *   "twopass"                hpass_generic + vpass_generic through an HBM scratch
  *   "color_convert_wide<a->b,..>", "color_convert_expand<a->b>", "color_convert<a->b,4px>"
