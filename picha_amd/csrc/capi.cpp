@@ -133,6 +133,10 @@ struct DeviceAxis {
         void *blob = nullptr;
         int32_t *rec = nullptr;    // [src + 8][2 * nacc]: weights (float bits), then completing output row or -1
         int32_t *range = nullptr;  // [dst][2]: first source row needed by this or any later output, last row so far
+        // ring aliasing of the one-row kind (the window has one row more than the reference's ring: the FIRST tap reads the
+        // window's LAST row, src/resize.cc:52-64,125-129): rec / range then refer to positions in a list of source rows in
+        // which that last row appears once more ahead of its window; src[position] = the source row (nullptr: no aliasing)
+        int32_t *src = nullptr;    // [list length + 8]
     };
     std::map<int, YRows> yrows;
     // row-staged kernel, x role: per column strip of 256 threads the first source pixel staged into LDS
@@ -517,44 +521,78 @@ int get_ystream(DeviceCtx *ctx, DeviceAxis *ay, int step, int taps, const Device
 // y % nacc while source rows left[y] .. left[y] + count[y] - 1 go by.  Representable when the vertical windows are
 // plain consecutive rows (no ring aliasing, src/resize.cc:52-64 quirk) and outputs y and y + nacc are never pending
 // at the same time.
-int get_yrows(DeviceCtx *ctx, DeviceAxis *ay, int nacc, const DeviceAxis::YRows **out) {
+// allow_look: accept tables whose first tap is ring-aliased onto the window's last row (lanczos / box at even integer scales: the
+// window is one row longer than the ring).  The reference's sum for such an output row is
+//     w0 * h(last) + w1 * h(left + 1) + ... + w[n-1] * h(last)          (row `left` itself is never read)
+// in that order, so the accumulator has to START from w0 * h(last).  The march therefore follows a LIST of source rows instead of
+// the rows themselves: every row in ascending order, and in front of row `left` of each aliased window that window's last row
+// once more, with a record that carries w0 in the output's accumulator (free and zero at that point: 0 + w0 * h is w0 * h) and
+// nothing else.  One extra horizontal pass per OUTPUT row; the kernel only needs the indirection position -> source row.
+int get_yrows(DeviceCtx *ctx, DeviceAxis *ay, int nacc, const DeviceAxis::YRows **out, bool allow_look = false) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    auto it = ay->yrows.find(nacc);
+    const int key = nacc + (allow_look ? 1000 : 0);
+    auto it = ay->yrows.find(key);
     if (it != ay->yrows.end()) { *out = &it->second; return PICHA_OK; }
     DeviceAxis::YRows yr;
     const AxisTaps &t = ay->host;
     const int dst = t.dst_size, src = t.src_size, T = t.taps;
-    bool ok = true;
+    bool ok = true, any_look = false;
+    std::vector<uint8_t> look(dst, 0);
     for (int y = 0; y < dst && ok; ++y) {
-        for (int j = 0; j < t.count[y] && ok; ++j)
-            if (t.eff[(size_t)y * T + j] != t.left[y] + j) ok = false;  // ring aliasing: not representable
+        const int n = t.count[y];
+        look[y] = allow_look && n >= 2 && t.eff[(size_t)y * T] == t.left[y] + n - 1;
+        for (int j = look[y] ? 1 : 0; j < n && ok; ++j)
+            if (t.eff[(size_t)y * T + j] != t.left[y] + j) ok = false;  // any other ring aliasing: not representable
+        any_look |= look[y] != 0;
         if (y >= nacc && t.left[y - nacc] + t.count[y - nacc] - 1 >= t.left[y]) ok = false;  // accumulator still busy
+        if (look[y] && y > 0 && t.left[y] < t.left[y - 1]) ok = false;                        // (list positions assume ascending windows)
     }
     yr.ok = ok;
     if (ok) {
-        const int rows = src + 8;  // ghost rows past the image: empty records
+        // list position of every source row, and of the extra entry in front of each aliased window
+        std::vector<int> pos_of_row(src + 1, 0), pos_of_init(dst, -1), src_of;
+        {
+            std::vector<std::vector<int>> starts(src);
+            for (int y = 0; y < dst; ++y)
+                if (look[y]) starts[t.left[y]].push_back(y);
+            for (int r = 0; r < src; ++r) {
+                for (int y : starts[r]) { pos_of_init[y] = (int)src_of.size(); src_of.push_back(t.left[y] + t.count[y] - 1); }
+                pos_of_row[r] = (int)src_of.size();
+                src_of.push_back(r);
+            }
+        }
+        const int rows = (int)src_of.size() + 8;  // ghost entries past the end: empty records, the last row again
         const size_t rec_words = (size_t)rows * 2 * nacc;
-        std::vector<int32_t> tab(rec_words + (size_t)dst * 2, 0);
+        std::vector<int32_t> tab(rec_words + (size_t)dst * 2 + (any_look ? rows : 0), 0);
         for (int r = 0; r < rows; ++r)
             for (int a = 0; a < nacc; ++a) tab[(size_t)r * 2 * nacc + nacc + a] = -1;
         for (int y = 0; y < dst; ++y) {
-            const int a = y % nacc;
-            for (int j = 0; j < t.count[y]; ++j) {
+            const int a = y % nacc, n = t.count[y];
+            for (int j = look[y] ? 1 : 0; j < n; ++j) {
                 const float w = t.weight[(size_t)y * T + j];
-                memcpy(&tab[(size_t)(t.left[y] + j) * 2 * nacc + a], &w, 4);
+                memcpy(&tab[(size_t)pos_of_row[t.left[y] + j] * 2 * nacc + a], &w, 4);
             }
-            tab[(size_t)(t.left[y] + t.count[y] - 1) * 2 * nacc + nacc + a] = y;
+            if (look[y]) memcpy(&tab[(size_t)pos_of_init[y] * 2 * nacc + a], &t.weight[(size_t)y * T], 4);
+            tab[(size_t)pos_of_row[t.left[y] + n - 1] * 2 * nacc + nacc + a] = y;
         }
         int32_t *range = tab.data() + rec_words;
-        for (int y = 0; y < dst; ++y) { range[2 * y] = t.left[y]; range[2 * y + 1] = t.left[y] + t.count[y] - 1; }
+        for (int y = 0; y < dst; ++y) {
+            range[2 * y] = look[y] ? pos_of_init[y] : pos_of_row[t.left[y]];
+            range[2 * y + 1] = pos_of_row[t.left[y] + t.count[y] - 1];
+        }
         for (int y = dst - 2; y >= 0; --y) range[2 * y] = std::min(range[2 * y], range[2 * (y + 1)]);   // see y_info.x
         for (int y = 1; y < dst; ++y) range[2 * y + 1] = std::max(range[2 * y + 1], range[2 * (y - 1) + 1]);
+        if (any_look) {
+            int32_t *sr = tab.data() + rec_words + (size_t)dst * 2;
+            for (int i = 0; i < rows; ++i) sr[i] = i < (int)src_of.size() ? src_of[i] : src - 1;
+        }
         HIP_TRY(hipMalloc(&yr.blob, tab.size() * sizeof(int32_t)));
         HIP_TRY(hipMemcpy(yr.blob, tab.data(), tab.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         yr.rec = static_cast<int32_t *>(yr.blob);
         yr.range = yr.rec + rec_words;
+        if (any_look) yr.src = yr.range + (size_t)dst * 2;
     }
-    auto ins = ay->yrows.emplace(nacc, yr);
+    auto ins = ay->yrows.emplace(key, yr);
     *out = &ins.first->second;
     return PICHA_OK;
 }
@@ -928,8 +966,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     if (!per_lane) return PICHA_OK;
     // where it is the default (same survey): windows of 26 taps and more (cfg3b: -3 % reference arithmetic, -10 % fma against the
     // row-staged kernel; greya -35 %); shorter windows only for batches that still fill the chip with a quarter of the
-    // accumulator kernel's waves (256 x 4K -> 512x288 grey: -11 %; 128 images: a tie)
-    if (opt_run == 0 && ktaps < 26 && !(kChannels[pixel] == 1 && n >= 192)) return PICHA_OK;
+    // accumulator kernel's waves (256 x 4K -> 512x288 grey: -11 %; 128 images: a tie; integer scales 6x / 8x: -9 .. -13 % at 128 images)
+    if (opt_run == 0 && ktaps < 26 && !(kChannels[pixel] == 1 && n >= (period == 1 ? 96 : 192))) return PICHA_OK;
     const DeviceAxis::RunTable *rt = nullptr;
     rc = get_runtable(ctx, ax, period, period_px, ktaps, wmode, is16, &rt);
     if (rc) return rc;
@@ -1588,9 +1626,19 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         for (int na : {4, 6}) {
             if (!acc_supported(pixel, ataps, na)) break;
             const DeviceAxis::YRows *cand = nullptr;
-            rc = get_yrows(ctx, ay, na, &cand);
+            // (r03) one-row ring aliasing — lanczos / box at even integer scales — is representable here: the kernel resamples
+            // the aliased row ahead of its march (get_yrows); the long-window variant does not do that
+            rc = get_yrows(ctx, ay, na, &cand, !acc_long);
             if (rc) return rc;
             if (cand->ok) { yr = cand; nacc = na; break; }
+        }
+        // ... where it was measured faster than the LDS-ring span kernel that serves such tables otherwise (r03, 64 x 4K sources,
+        // profiles/r03_survey_ring_aliasing.txt): always beyond 32 vertical taps (no span instantiation: lanczos 8x went through
+        // the two-pass kernels, 6-17x slower); three or four channels from 16 taps (lanczos 4x: -11 .. -22 %, 6x: 1.5-2.3x);
+        // greya from 24, grey from 26 (the ring of one float per lane is cheap: a tie at 6x); box and lanczos 2x stay on the ring
+        if (yr && yr->src && opt_acc != 1 && opt_path != 4) {
+            const int ty = ay->host.taps, ch = kChannels[pixel];
+            if (!(ty > 32 || (ch >= 3 && ty >= 16) || (ch == 2 && ty >= 24) || (ch == 1 && ty >= 26))) { yr = nullptr; nacc = 0; }
         }
         // two outputs per lane (r02): the union of both windows is loaded and converted once; option "acc_p2": 0 auto (where
         // acc_p2_preferred says it was measured faster), 1 whenever a shape exists, 2 never
@@ -1673,7 +1721,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         p.y_taps = ay->host.taps; p.y_pad = ay->y_pad;
         p.ring_slots = ring;
         p.xcd_remap = opt_xcd == 1 ? 1 : 0;
-        if (use_acc) { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; p.x_per_lane = acc_per_lane; p.x_step = acc_x_step; p.xch = acc_xch ? 1 : 0; }
+        if (use_acc) { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.yrow_src = yr->src; p.nacc = nacc; p.x_per_lane = acc_per_lane; p.x_step = acc_x_step; p.xch = acc_xch ? 1 : 0; }
         if (epi) { p.epi_on = 1; p.epi_pixel = d0.pixel; p.epi_r = epi->r; p.epi_g = epi->g; p.epi_b = epi->b; if (epi_used) *epi_used = true; }
         // row chunks: enough waves to fill 256 CUs several times over (~32 K), but every chunk re-resamples the `ring`
         // source rows above its first output: keep that halo under ~6 % of the chunk's own source rows unless the

@@ -95,6 +95,10 @@ struct FusedParams {
     // COMPLETES with this source row (or -1); per output row {first source row needed by it or any later row, last}
     const int32_t *yrow_rec;    // [src_h + 8][2 * nacc]
     const int32_t *yrow_range;  // [dst_h][2]
+    // ring aliasing of the one-row kind (optional, accumulator kernel only): the records and ranges then refer to positions in a
+    // LIST of source rows — every row in order, plus, ahead of each aliased window, the window's last row once more, whose record
+    // carries the aliased first tap's weight — and yrow_src[position] is the source row to resample (nullptr: position == row)
+    const int32_t *yrow_src;    // [list length + 8] or nullptr
     int nacc;
     int xch;  // accumulator kernel, neighbour-exchange form: a lane loads only its own x_step * x_per_lane pixels (uniform-base x table)
     WorkList work;  // accumulator kernel only: explicit work items / persistent launch

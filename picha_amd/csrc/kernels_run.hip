@@ -387,10 +387,13 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // (30 + the half pixel) at filter scale 1, for every filter but box / triangle.  Survey over formats (r03, 128 x 4K -> 512x288,
 // profiles/r03_survey_run_kernel.txt): grey 31 taps -13 % against the row-staged kernel (fma -20 %), greya 31 taps -35 % (two
 // outputs per lane), grey 21 taps -11 % on 256 images and a tie on 128; rgb / rgba / r16 were ties (-3 .. +4 %) and are not
-// instantiated (rgba at 31 taps does not fit the edge kernel's LDS block either).
+// instantiated (rgba at 31 taps does not fit the edge kernel's LDS block either).  Integer scales with long windows (period 1; 128 x 4K ->
+// 640x360 / 480x270, picha's defaults: 17 / 23 taps; profiles/r03_survey_run_kernel_integer_scales.txt): grey -9 % / -13 % against the
+// accumulator kernel (fma -14 % / -4 %); greya, rgb, rgba -2 .. +7 %: not instantiated.  (lanczos at those scales is ring-aliased in y:
+// the accumulator kernel's row list serves it, capi.cpp get_yrows.)
 #define PICHA_RUN_LIST_0(X) /* rgb */
 #define PICHA_RUN_LIST_1(X) /* rgba */
-#define PICHA_RUN_LIST_2(X) /* grey */ X(2, 15, 21, 2) X(2, 15, 21, 4) X(2, 15, 21, 8) X(2, 15, 31, 2) X(2, 15, 31, 4)
+#define PICHA_RUN_LIST_2(X) /* grey */ X(1, 6, 17, 4) X(1, 8, 23, 4) X(1, 8, 23, 8) X(2, 15, 21, 2) X(2, 15, 21, 4) X(2, 15, 21, 8) X(2, 15, 31, 2) X(2, 15, 31, 4)
 #define PICHA_RUN_LIST_3(X) /* greya */ X(2, 15, 21, 2) X(2, 15, 31, 2) X(2, 15, 31, 4)
 #define PICHA_RUN_LIST_4(X) /* r16 */
 #define PICHA_RUN_LIST_5(X) /* r16g16 */

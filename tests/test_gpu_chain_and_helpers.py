@@ -209,15 +209,18 @@ def test_row_staged_downscale_kernel_matches_oracle(case):
             N.check(N.lib().picha_hip_set_option(k, 0))
 
 
-RUN_CASES = [
-    ("grey", (960, 270), (128, 64), "lanczos", 1.0, 31),      # cfg3b's structure: 7.5x in x (period 2 / 15 pixels), 4.2x in y
-    ("grey", (960, 540), (128, 72), "cubic", 0.70, 21),       # 7.5x both ways, picha's default options (21 taps)
-    ("grey", (1920, 90), (256, 37), "mitchel", 1.0, 31),      # two waves per row (four outputs per lane), odd output height
-    ("grey", (975, 300), (130, 40), "catmulrom", 0.70, 21),   # the last lane's run hangs over the row end (130 = 32 * 4 + 2)
-    ("greya", (960, 270), (128, 64), "lanczos", 1.0, 31),     # two-byte pixels: two (default) or four outputs per lane
-    ("greya", (1950, 150), (260, 20), "cubic", 0.70, 21),     # five row pieces of 64 lanes, the last one ragged
+RUN_CASES = [   # pixel, source, destination, filter, filter scale, (period in outputs, period in source pixels, taps)
+    ("grey", (960, 270), (128, 64), "lanczos", 1.0, (2, 15, 31)),      # cfg3b's structure: 7.5x in x (period 2 / 15 pixels), 4.2x in y
+    ("grey", (960, 540), (128, 72), "cubic", 0.70, (2, 15, 21)),       # 7.5x both ways, picha's default options (21 taps)
+    ("grey", (1920, 90), (256, 37), "mitchel", 1.0, (2, 15, 31)),      # two waves per row (four outputs per lane), odd output height
+    ("grey", (975, 300), (130, 40), "catmulrom", 0.70, (2, 15, 21)),   # the last lane's run hangs over the row end (130 = 32 * 4 + 2)
+    ("greya", (960, 270), (128, 64), "lanczos", 1.0, (2, 15, 31)),     # two-byte pixels: two (default) or four outputs per lane
+    ("greya", (1950, 150), (260, 20), "cubic", 0.70, (2, 15, 21)),     # five row pieces of 64 lanes, the last one ragged
+    ("grey", (1920, 180), (320, 30), "cubic", 0.70, (1, 6, 17)),       # integer scale, period 1: 6x, 17 taps
+    ("grey", (2048, 240), (256, 41), "cubic", 0.70, (1, 8, 23)),       # 8x, 23 taps: four or eight outputs per lane
 ]
-RUN_PER_LANE = {("grey", 21): (0, 2, 4, 8), ("grey", 31): (0, 2, 4), ("greya", 21): (0, 2), ("greya", 31): (0, 2, 4)}
+RUN_PER_LANE = {("grey", 2, 21): (0, 2, 4, 8), ("grey", 2, 31): (0, 2, 4), ("greya", 2, 21): (0, 2), ("greya", 2, 31): (0, 2, 4),
+                ("grey", 1, 17): (0, 4), ("grey", 1, 23): (0, 4, 8)}
 
 
 @pytest.mark.parametrize("case", RUN_CASES, ids=lambda c: "%s-%dx%d-%s" % (c[0], c[1][0], c[1][1], c[3]))
@@ -228,7 +231,7 @@ def test_run_kernel_matches_oracle(case):
     strides, a device batch, and the fma flavour; run = 2 gives the kernel it replaces, which must agree byte for byte."""
     from picha_amd.device import DeviceBatch, resize_batch
     import torch
-    pixel, (sw, sh), (dw, dh), filt, fscale, taps = case
+    pixel, (sw, sh), (dw, dh), filt, fscale, (period, period_px, taps) = case
     ch = N.PIXEL_CHANNELS[pixel]
     rng = np.random.default_rng(sw + 17 * dh)
     img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 4, 8])))
@@ -237,14 +240,14 @@ def test_run_kernel_matches_oracle(case):
     keys = (b"run", b"per_lane", b"row_chunks", b"work", b"numerics", b"block_waves")
     try:
         N.check(N.lib().picha_hip_set_option(b"run", 1))
-        for per_lane in RUN_PER_LANE[(pixel, taps)]:
+        for per_lane in RUN_PER_LANE[(pixel, period, taps)]:
             for chunks, work in ((0, 0), (1, 3), (3, 1), (2, 2)):
                 N.check(N.lib().picha_hip_set_option(b"per_lane", per_lane))
                 N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
                 N.check(N.lib().picha_hip_set_option(b"work", work))
                 got = picha.resizeSync(img, opts)
                 name = N.lib().picha_hip_last_kernel().decode()
-                assert name.startswith("resize_run<ch%d,u8,Q2,PX15,TX%d,P%d," % (ch, taps, per_lane or (4 if ch == 1 else 2))), name
+                assert name.startswith("resize_run<ch%d,u8,Q%d,PX%d,TX%d,P%d," % (ch, period, period_px, taps, per_lane or (4 if ch == 1 else 2))), name
                 assert "+ resize_edges<" in name, name
                 assert max_code_diff(got, want) == 0, (case, per_lane, chunks, work, name)
         for k in keys[1:]:

@@ -428,14 +428,17 @@ def test_host_entry_points_do_not_leak_per_thread_resources():
         for t in ts:
             t.join()
 
-    burst(8)  # fills the pool (at most 4 idle lanes are kept)
+    for _ in range(3):
+        burst(8)  # fills the pool: as many lanes as calls were ever in flight at once (<= 8 here, ~4 MB of HBM each) stay leased out
     torch.cuda.synchronize()
     free0, _ = torch.cuda.mem_get_info()
     for _ in range(12):
         burst(8)   # 96 more threads, each dies after one call
     torch.cuda.synchronize()
     free1, _ = torch.cuda.mem_get_info()
-    assert free0 - free1 < 16 << 20, (free0, free1)   # thread_local lanes would have leaked ~300 MB here
+    # a later burst may overlap more than the first three did and add the missing lanes (<= 8 x 4 MB in all);
+    # thread_local lanes would have leaked ~400 MB here
+    assert free0 - free1 < 48 << 20, (free0, free1)
 
 
 def test_dimensions_whose_row_does_not_fit_an_int_are_refused():
@@ -814,6 +817,68 @@ def test_long_window_accumulator_kernel(pixel):
         got = picha_amd.resizeSync(img, opts)
         assert max_code_diff(got, exp) <= 1, (pixel, sw, "fma", N.lib().picha_hip_last_kernel())
         set_opt("numerics", 0)
+
+
+@pytest.mark.parametrize("pixel", PIXELS)
+def test_ring_aliased_tables_on_the_accumulator_kernel_match_oracle(pixel):
+    """r03: lanczos and box at even integer scales make the reference's ring one row short (src/resize.cc:52-64): the first tap of
+    every output row reads the window's LAST row.  The accumulator kernel follows a row LIST in which that row appears once more
+    ahead of its window (capi.cpp, get_yrows) instead of leaving such tables to the LDS-ring span kernel or, beyond 32 vertical
+    taps, to the two-pass kernels.  Forced ("acc" = 1) and default, every chunking, one and two outputs per lane, both numerics,
+    against the oracle — and against the span kernel byte for byte."""
+    rng = np.random.default_rng(4100 + PIXELS.index(pixel))
+    served = 0
+    for (sw, sh, dw, dh, filt) in [(640, 96, 320, 48, "lanczos"),     # 2x: 9 taps on a ring of 8
+                                   (512, 128, 128, 32, "lanczos"),    # 4x: 17 on 16
+                                   (768, 192, 128, 32, "lanczos"),    # 6x: 25 on 24
+                                   (1024, 264, 128, 33, "lanczos"),   # 8x: 33 on 32 (no span instantiation: two-pass before r03)
+                                   (512, 64, 128, 16, "box"),         # 4x box: 5 on 4
+                                   (300, 77, 150, 19, "lanczos")]:    # 2x horizontally, 4.05x vertically: no aliasing in y
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8])))
+        exp = oracle_resize(img, dw, dh, filt, 1.0)
+        opts = {"width": dw, "height": dh, "filter": filt}
+        try:
+            set_opt("acc", 2)
+            ring = picha_amd.resizeSync(img, opts)
+            ring_name = N.lib().picha_hip_last_kernel().decode()
+            assert max_code_diff(ring, exp) == 0, (pixel, sw, filt, ring_name)
+            for acc, chunks, p2 in ((1, 0, 0), (1, 1, 0), (1, 3, 1), (0, 0, 0)):
+                set_opt("acc", acc)
+                set_opt("row_chunks", chunks)
+                set_opt("acc_p2", p2)
+                got = picha_amd.resizeSync(img, opts)
+                name = N.lib().picha_hip_last_kernel().decode()
+                if acc == 1:
+                    assert name.startswith("resize_acc<"), (pixel, sw, filt, name)
+                    served += 1
+                assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, filt, acc, chunks, name)
+            set_opt("acc", 1)
+            set_opt("numerics", 1)
+            got = picha_amd.resizeSync(img, opts)
+            assert max_code_diff(got, exp) <= 1, (pixel, sw, filt, "fma", N.lib().picha_hip_last_kernel())
+        finally:
+            for k in ("acc", "row_chunks", "acc_p2", "numerics"):
+                set_opt(k, 0)
+    assert served >= 15, served
+
+
+def test_ring_aliased_long_windows_take_the_accumulator_kernel_by_default():
+    """Planner rule of r03 (profiles/r03_survey_ring_aliasing.txt): beyond 32 vertical taps always (lanczos 8x: was two-pass), three
+    or four channels from 16 taps, greya from 24, grey from 26; box and lanczos 2x stay on the LDS ring."""
+    rng = np.random.default_rng(4200)
+    for pixel, sw, sh, dw, dh, filt, want in [
+        ("rgba", 1024, 264, 128, 33, "lanczos", "resize_acc<ch4,u8,TX36,NACC6"),
+        ("grey", 1024, 264, 128, 33, "lanczos", "resize_acc<ch1,u8,TX36,NACC6"),
+        ("rgb", 512, 128, 128, 32, "lanczos", "resize_acc<ch3,u8,TX"),
+        ("grey", 512, 128, 128, 32, "lanczos", "resize_span<ch1,u8"),
+        ("rgba", 640, 96, 320, 48, "lanczos", "resize_span<ch4,u8"),
+        ("rgba", 512, 64, 128, 16, "box", "resize_span<ch4,u8"),
+    ]:
+        img = rand_image(rng, sw, sh, pixel)
+        got = picha_amd.resizeSync(img, {"width": dw, "height": dh, "filter": filt})
+        name = N.lib().picha_hip_last_kernel().decode()
+        assert name.startswith(want), (pixel, sw, filt, name)
+        assert max_code_diff(got, oracle_resize(img, dw, dh, filt, 1.0)) == 0, name
 
 
 @pytest.mark.parametrize("work", [1, 2])
