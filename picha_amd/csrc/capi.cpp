@@ -1626,9 +1626,9 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         for (int na : {4, 6}) {
             if (!acc_supported(pixel, ataps, na)) break;
             const DeviceAxis::YRows *cand = nullptr;
-            // (r03) one-row ring aliasing — lanczos / box at even integer scales — is representable here: the kernel resamples
-            // the aliased row ahead of its march (get_yrows); the long-window variant does not do that
-            rc = get_yrows(ctx, ay, na, &cand, !acc_long);
+            // (r03) one-row ring aliasing — lanczos / box at even integer scales — is representable here: the march follows a row
+            // list in which the aliased row appears once more ahead of its window (get_yrows); both accumulator kernels do
+            rc = get_yrows(ctx, ay, na, &cand, true);
             if (rc) return rc;
             if (cand->ok) { yr = cand; nacc = na; break; }
         }

@@ -832,6 +832,7 @@ def test_ring_aliased_tables_on_the_accumulator_kernel_match_oracle(pixel):
                                    (512, 128, 128, 32, "lanczos"),    # 4x: 17 on 16
                                    (768, 192, 128, 32, "lanczos"),    # 6x: 25 on 24
                                    (1024, 264, 128, 33, "lanczos"),   # 8x: 33 on 32 (no span instantiation: two-pass before r03)
+                                   (1536, 300, 128, 25, "lanczos"),   # 12x: 49 on 48 — the long-window accumulator kernel
                                    (512, 64, 128, 16, "box"),         # 4x box: 5 on 4
                                    (300, 77, 150, 19, "lanczos")]:    # 2x horizontally, 4.05x vertically: no aliasing in y
         img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8])))
@@ -849,7 +850,7 @@ def test_ring_aliased_tables_on_the_accumulator_kernel_match_oracle(pixel):
                 got = picha_amd.resizeSync(img, opts)
                 name = N.lib().picha_hip_last_kernel().decode()
                 if acc == 1:
-                    assert name.startswith("resize_acc<"), (pixel, sw, filt, name)
+                    assert name.startswith("resize_acc<") or (sw == 1536 and name.startswith("resize_acc_long<")), (pixel, sw, filt, name)
                     served += 1
                 assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, filt, acc, chunks, name)
             set_opt("acc", 1)
@@ -859,7 +860,7 @@ def test_ring_aliased_tables_on_the_accumulator_kernel_match_oracle(pixel):
         finally:
             for k in ("acc", "row_chunks", "acc_p2", "numerics"):
                 set_opt(k, 0)
-    assert served >= 15, served
+    assert served >= 18, served
 
 
 def test_ring_aliased_long_windows_take_the_accumulator_kernel_by_default():
@@ -868,6 +869,7 @@ def test_ring_aliased_long_windows_take_the_accumulator_kernel_by_default():
     rng = np.random.default_rng(4200)
     for pixel, sw, sh, dw, dh, filt, want in [
         ("rgba", 1024, 264, 128, 33, "lanczos", "resize_acc<ch4,u8,TX36,NACC6"),
+        ("rgb", 1536, 300, 128, 25, "lanczos", "resize_acc_long<ch3,u8,TX"),
         ("grey", 1024, 264, 128, 33, "lanczos", "resize_acc<ch1,u8,TX36,NACC6"),
         ("rgb", 512, 128, 128, 32, "lanczos", "resize_acc<ch3,u8,TX"),
         ("grey", 512, 128, 128, 32, "lanczos", "resize_span<ch1,u8"),
