@@ -14,11 +14,10 @@
 //   * no LDS, no barrier; the vertical part is the accumulator kernel's (per-source-row records, NACC pending output rows
 //     in registers), so every sum adds the reference's products in the reference's order: bit-exact in the reference flavour
 //     (src/resize.cc:110-117, 125-129).
-// The few columns whose windows are clipped by an image edge (renormalised weights: 4 of 512 for cfg3b) are left out by the
-// march (masked stores) and computed afterwards by the wave that holds them, one lane per output PIXEL of the chunk: the
-// reference's double sum straight from the source with that column's own weights (edge_pass below).  (A separate kernel for
-// them — one lane per pixel, lanes along y — took 0.17 ms on cfg3b against 0.62 for the march: every lane of a load touched
-// another cache line and re-fetched the lines of the rows its neighbours had just used.)
+// The few columns whose windows are clipped by an image edge (renormalised weights: 4 of 512 for cfg3b) come out of the march
+// with the canonical weights and are then OVERWRITTEN by resize_edges_kernel (same stream, launched after it): the reference's
+// double sum with those columns' own weights, from a stash of raw pixels that the two lanes holding such columns leave behind
+// (edge_pass below; how the other forms of this step measured: profiles/r03_ab_run_kernel.txt).
 #define PICHA_SPAN_ONLY 1
 #include "kernels_impl.inc"
 #ifndef PICHA_RUN_NB
