@@ -598,16 +598,17 @@ int get_yrows(DeviceCtx *ctx, DeviceAxis *ay, int nacc, const DeviceAxis::YRows 
 }
 
 // Run kernel (kernels_run.hip), x role.  The table is periodic with `period` outputs / `period_px` source pixels when, for the
-// canonical window start  c(x) = x_base + (x / period) * period_px + ((x % period) * period_px) / period,  every output's taps lie
+// canonical window start  c(x) = x_base + (x / period) * period_px + ((x % period) * period_px + ceil * (period - 1)) / period  (offsets
+// inside a period rounded down or up: whichever needs fewer padding taps),  every output's taps lie
 // inside [c(x), c(x) + taps) and its zero-padded weights equal those of the middle period's output x % period bit for bit.  Columns
 // that fail (windows clipped by an image edge carry renormalised weights) must be a few at either end of the row — [0, c0) and
 // [c1, dst), at most kMaxRunEdge each — which the kernel computes one pixel per lane from the generic tables.  `pad_to` > 0: pad the window to that many taps (an instantiated count).
 // wmode: 0 reference weights, 1 times 1/max (fma flavour), 2 times 2^22 (formats that unpack through the denormal form).
 constexpr int kMaxRunEdge = 16;
-int run_table_taps(const AxisTaps &t, int period, int period_px, int *x_base_out) {
+int run_table_taps(const AxisTaps &t, int period, int period_px, int ceil_off, int *x_base_out) {
     const int dst = t.dst_size;
     if (dst < 4 * period) return 0;
-    auto offg = [&](int x) { return (x / period) * period_px + ((x % period) * period_px) / period; };
+    auto offg = [&](int x) { return (x / period) * period_px + ((x % period) * period_px + ceil_off * (period - 1)) / period; };
     const int mid = (dst / 2) / period * period;
     int xb = INT32_MAX, tx = 0;
     for (int q = 0; q < period; ++q) xb = std::min(xb, t.left[mid + q] - offg(mid + q));
@@ -615,22 +616,22 @@ int run_table_taps(const AxisTaps &t, int period, int period_px, int *x_base_out
     *x_base_out = xb;
     return tx;
 }
-int get_runtable(DeviceCtx *ctx, DeviceAxis *ax, int period, int period_px, int pad_to, int wmode, int is16, const DeviceAxis::RunTable **out) {
+int get_runtable(DeviceCtx *ctx, DeviceAxis *ax, int period, int period_px, int ceil_off, int pad_to, int wmode, int is16, const DeviceAxis::RunTable **out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
-    auto key = std::make_tuple(period, period_px, pad_to, wmode + 4 * is16);
+    auto key = std::make_tuple(period, period_px, pad_to, wmode + 4 * is16 + 8 * ceil_off);
     auto it = ax->runtables.find(key);
     if (it != ax->runtables.end()) { *out = &it->second; return PICHA_OK; }
     DeviceAxis::RunTable rt;
     const AxisTaps &t = ax->host;
     const int dst = t.dst_size, T = t.taps;
     int xb = 0;
-    const int tx_min = run_table_taps(t, period, period_px, &xb);
+    const int tx_min = run_table_taps(t, period, period_px, ceil_off, &xb);
     const int TX = std::max(tx_min, pad_to);
     bool ok = tx_min > 0 && TX <= 64;
     std::vector<float> canon;
     int c0 = 0, c1 = dst;
     if (ok) {
-        auto offg = [&](int x) { return (x / period) * period_px + ((x % period) * period_px) / period; };
+        auto offg = [&](int x) { return (x / period) * period_px + ((x % period) * period_px + ceil_off * (period - 1)) / period; };
         const float inv = is16 ? 1.0f / 65535.0f : 1.0f / 255.0f;
         auto padded = [&](int x, float *v) {  // false: the taps do not fit the canonical window
             const int first = t.left[x] - (xb + offg(x));
@@ -903,6 +904,7 @@ long g_opt_fuse = 0;  // chained convert+resize: 0 auto (one fused kernel where 
 long g_opt_rows = 0;  // row-staged (LDS) downscale kernel: 0 auto, 1 whenever it applies, 2 never
 
 long g_opt_run = 0;   // run kernel (periodic tap tables, kernels_run.hip): 0 auto, 1 whenever it applies, 2 never
+long g_opt_run_round = 0;  // its window offsets inside a period: 0 auto (the shorter window), 1 rounded down, 2 rounded up
 
 // Run kernel for one equal-geometry group: downscales whose x scale is a ratio of small integers with a long window.
 // *used = false: not applicable, the caller goes on with the other kernels.
@@ -910,10 +912,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     *used = false;
     const picha_image &s0 = src[0], &d0 = dst[0];
     const int pixel = s0.pixel;
-    long opt_run, opt_numerics, opt_chunks, opt_per_lane, opt_work, opt_work_tail, opt_work_tail_div, opt_bw;
+    long opt_run, opt_run_round, opt_numerics, opt_chunks, opt_per_lane, opt_work, opt_work_tail, opt_work_tail_div, opt_bw;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
-        opt_run = g_opt_run; opt_numerics = g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
+        opt_run = g_opt_run; opt_run_round = g_opt_run_round; opt_numerics = g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
         opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
         opt_bw = g_opt_block_waves;
     }
@@ -938,15 +940,12 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     rc = get_axis(ctx, filter, fscale, s0.height, d0.height, &ay_ref);
     if (rc) return rc;
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
-    int xb = 0;
-    const int tx_min = run_table_taps(ax->host, period, period_px, &xb);
-    if (tx_min <= 0) return PICHA_OK;
     const int fma = opt_numerics == 1 ? 1 : 0;
     const int is16 = pixel >= PICHA_R16;
     const int wmode = fma ? 1 : exact_unpack_scaled(kChannels[pixel], is16 != 0) ? 2 : 0;
     // shape: the smallest instantiated tap count >= the table's, outputs per lane as instantiated ("per_lane" forces one)
     const DeviceAxis::YRows *yr = nullptr;
-    int nacc = 0, per_lane = 0, ktaps = 0;
+    int nacc = 0, per_lane = 0, ktaps = 0, ceil_off = 0;
     for (int na : {4, 6}) {
         const DeviceAxis::YRows *cand = nullptr;
         rc = get_yrows(ctx, ay, na, &cand);
@@ -954,22 +953,31 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         if (cand->ok) { yr = cand; nacc = na; break; }
     }
     if (!yr) return PICHA_OK;
-    // outputs per lane: four for single-channel pixels, two for the others (r03 survey, profiles/r03_survey_run_kernel.txt)
+    // window offsets inside a period rounded down or up (7.5x, 30 taps: 31 with the offsets 0 / 7, 30 with 0 / 8): the form with the
+    // shorter window first; outputs per lane: four for single-channel pixels, two for the others (r03 survey,
+    // profiles/r03_survey_run_kernel.txt)
+    int tx_of[2], xb_unused = 0;
+    for (int c = 0; c < 2; ++c) tx_of[c] = run_table_taps(ax->host, period, period_px, c, &xb_unused);
+    if (tx_of[0] <= 0) return PICHA_OK;
     static const int order1[] = {4, 8, 2}, order2[] = {2, 4, 8};
-    for (int tx = tx_min; tx <= tx_min + 3 && !per_lane; ++tx)
-        for (int pl : (kChannels[pixel] == 1 ? order1 : order2)) {
-            if (opt_per_lane > 0 && pl != opt_per_lane) continue;
-            if (pl % period || !run_kernel_supported(pixel, period, period_px, tx, pl, nacc)) continue;
-            per_lane = pl; ktaps = tx;
-            break;
-        }
+    for (int k = 0; k < 2 && !per_lane; ++k) {
+        const int c = (tx_of[1] > 0 && tx_of[1] < tx_of[0]) ? 1 - k : k;   // the shorter window first
+        if (tx_of[c] <= 0 || (period == 1 && c == 1) || (opt_run_round != 0 && opt_run_round != c + 1)) continue;
+        for (int tx = tx_of[c]; tx <= tx_of[c] + 3 && !per_lane; ++tx)
+            for (int pl : (kChannels[pixel] == 1 ? order1 : order2)) {
+                if (opt_per_lane > 0 && pl != opt_per_lane) continue;
+                if (pl % period || !run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c)) continue;
+                per_lane = pl; ktaps = tx; ceil_off = c;
+                break;
+            }
+    }
     if (!per_lane) return PICHA_OK;
     // where it is the default (same survey): windows of 26 taps and more (cfg3b: -3 % reference arithmetic, -10 % fma against the
     // row-staged kernel; greya -35 %); shorter windows only for batches that still fill the chip with a quarter of the
     // accumulator kernel's waves (256 x 4K -> 512x288 grey: -11 %; 128 images: a tie; integer scales 6x / 8x: -9 .. -13 % at 128 images)
     if (opt_run == 0 && ktaps < 26 && !(kChannels[pixel] == 1 && n >= (period == 1 ? 96 : 192))) return PICHA_OK;
     const DeviceAxis::RunTable *rt = nullptr;
-    rc = get_runtable(ctx, ax, period, period_px, ktaps, wmode, is16, &rt);
+    rc = get_runtable(ctx, ax, period, period_px, ceil_off, ktaps, wmode, is16, &rt);
     if (rc) return rc;
     if (!rt->ok) return PICHA_OK;
 
@@ -979,7 +987,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     int stash_words = 0, stash_org[2] = {0, 0};
     if (has_edges) {
         const int bpp = kBytes[pixel];
-        const int span = ((per_lane - 1) / period) * period_px + (((per_lane - 1) % period) * period_px) / period + ktaps;  // RunCfg::SPAN
+        const int span = ((per_lane - 1) / period) * period_px + (((per_lane - 1) % period) * period_px + ceil_off * (period - 1)) / period + ktaps;  // RunCfg::SPAN
         stash_words = bpp % 4 == 0 ? span * bpp / 4 : (span * bpp + 3) / 4 + 1;                                        // RunCfg::NW
         if (x_groups < 2) return PICHA_OK;
         for (int i = 0; i < n; ++i)
@@ -1055,7 +1063,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     p.src_stride = s0.stride; p.dst_stride = d0.stride;
     p.src_w = s0.width; p.src_h = s0.height; p.dst_w = d0.width; p.dst_h = d0.height;
     p.src_bytes = (unsigned)src_span; p.dst_bytes = (unsigned)dst_span;
-    p.period = period; p.period_px = period_px; p.x_taps = ktaps; p.x_per_lane = per_lane; p.x_base = rt->x_base;
+    p.period = period; p.period_px = period_px; p.x_taps = ktaps; p.x_per_lane = per_lane; p.x_base = rt->x_base; p.off_ceil = ceil_off;
     p.x_groups = x_groups;
     p.x_canon = rt->canon;
     p.fma = fma;
@@ -2129,6 +2137,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "sym") == 0) { g_opt_sym = value; return PICHA_OK; }
     if (strcmp(key, "rows") == 0) { g_opt_rows = value; return PICHA_OK; }
     if (strcmp(key, "run") == 0) { g_opt_run = value; return PICHA_OK; }
+    if (strcmp(key, "run_round") == 0) { g_opt_run_round = value; return PICHA_OK; }
     if (strcmp(key, "fuse") == 0) { g_opt_fuse = value; return PICHA_OK; }
     if (strcmp(key, "cc_mode") == 0) { g_opt_cc_mode = value; return PICHA_OK; }
     if (strcmp(key, "block_waves") == 0) { g_opt_block_waves = value; return PICHA_OK; }
@@ -2158,6 +2167,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "sym") == 0) return g_opt_sym;
     if (strcmp(key, "rows") == 0) return g_opt_rows;
     if (strcmp(key, "run") == 0) return g_opt_run;
+    if (strcmp(key, "run_round") == 0) return g_opt_run_round;
     if (strcmp(key, "fuse") == 0) return g_opt_fuse;
     if (strcmp(key, "cc_mode") == 0) return g_opt_cc_mode;
     if (strcmp(key, "block_waves") == 0) return g_opt_block_waves;

@@ -237,9 +237,9 @@ struct RunParams {
     int n_images;
     // x axis: the table repeats every `period` outputs / `period_px` source pixels; a lane owns x_per_lane (a multiple of the
     // period) consecutive outputs; output x's window of x_taps pixels starts at x_base + (x / period) * period_px +
-    // ((x % period) * period_px) / period; x_canon = the period's weights [period][x_taps] in the kernel's flavour (plain,
+    // ((x % period) * period_px + off_ceil * (period - 1)) / period; x_canon = the period's weights [period][x_taps] in the kernel's flavour (plain,
     // 1/max folded for fma, or scaled by 2^22 where the format unpacks through the denormal form)
-    int period, period_px, x_taps, x_per_lane, x_base, x_groups;
+    int period, period_px, x_taps, x_per_lane, x_base, x_groups, off_ceil;
     const float *x_canon;
     int fma;
     const int32_t *yrow_rec, *yrow_range;  // the accumulator kernel's per-source-row records
@@ -264,7 +264,7 @@ struct RunParams {
     const float *y_weight;  // [dst_h][y_taps]
     int y_taps;
 };
-bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc);
+bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc, int off_ceil);
 hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s, const char **kernel_name);
 hipError_t launch_resize_edges_kernel(int pixel, const RunParams &p, hipStream_t s);  // after the run kernel, same stream: the columns outside [cx0, cx1)
 int run_kernel_resident_blocks(int pixel, const RunParams &p);

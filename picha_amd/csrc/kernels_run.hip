@@ -28,12 +28,13 @@ namespace picha_hip {
 namespace {
 
 // first pixel of output o's window relative to the window of output 0 of the same lane
-constexpr int run_off(int Q, int PX, int o) { return (o / Q) * PX + ((o % Q) * PX) / Q; }
+// (RC = 1: the offsets inside a period round up instead of down — 7.5x with 30 taps: windows at 0, 8, 15, 23 need no padding tap)
+constexpr int run_off(int Q, int PX, int o, int RC = 0) { return (o / Q) * PX + ((o % Q) * PX + RC * (Q - 1)) / Q; }
 
-template <int CH, bool S16, int Q, int PX, int TX, int P> struct RunCfg {
+template <int CH, bool S16, int Q, int PX, int TX, int P, int RC = 0> struct RunCfg {
     static constexpr int BPS = Sample<S16>::kBytes;
     static constexpr int BPP = CH * BPS;
-    static constexpr int SPAN = run_off(Q, PX, P - 1) + TX;  // source pixels a lane reads per row
+    static constexpr int SPAN = run_off(Q, PX, P - 1, RC) + TX;  // source pixels a lane reads per row
     static constexpr bool WORDS = (BPP % 4 == 0);
     static constexpr bool BYTESPAN = !WORDS;
     static constexpr bool BROT = !WORDS;                     // sub-dword pixels: aligned dwords + v_alignbyte by the lane's byte phase
@@ -181,9 +182,9 @@ __global__ __launch_bounds__(64) void resize_edges_kernel(RunParams p) {
     edge_pass<CH, S16, TXE>(p, stash_rs, int(st_stride), p.stash_org[side], dst_rs, lane, edge_lds, xa0, na, y0, y1);
 }
 
-template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC, bool FMA>
+template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC, bool FMA, int RC = 0>
 __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
-    using C = RunCfg<CH, S16, Q, PX, TX, P>;
+    using C = RunCfg<CH, S16, Q, PX, TX, P, RC>;
     static_assert(P % Q == 0, "a lane owns whole periods");
     constexpr int NRAW = C::NW;
     constexpr int NB = NRAW <= 16 ? PICHA_RUN_NB : 2;  // row buffers
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
             else unpack_span_px<C, CH, S16, FMA>(cur, q, u);
 #pragma unroll
             for (int o = 0; o < P; ++o) {
-                const int j = q - run_off(Q, PX, o);  // tap index of window pixel q for output o
+                const int j = q - run_off(Q, PX, o, RC);  // tap index of window pixel q for output o
                 if (j >= 0 && j < TX) {
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
@@ -357,12 +358,12 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     }, run_item);
 }
 
-template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC>
+template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC, int RC>
 hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
-    const void *k = p.fma ? reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true>)
-                          : reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false>);
+    const void *k = p.fma ? reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true, RC>)
+                          : reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false, RC>);
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 4;
-    const size_t lds = p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, Q, PX, TX, P>::NW + 3) / 4 * 4) : 0;   // the stash staging of the edge lanes
+    const size_t lds = p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, Q, PX, TX, P, RC>::NW + 3) / 4 * 4) : 0;   // the stash staging of the edge lanes
     if (p.resident_query) {
         int per_cu = 0, dev = 0, cus = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * bw, lds);
@@ -373,15 +374,16 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
     }
     dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
     if (p.work.items) grid = dim3(p.work.queue ? (unsigned)p.n_chunks : 8u * (unsigned)p.work.items_per_xcd, 1, 1);
-    if (p.fma) resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true><<<grid, 64 * bw, lds, s>>>(p);
-    else resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false><<<grid, 64 * bw, lds, s>>>(p);
-    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_run<ch%d,%s,Q%d,PX%d,TX%d,P%d,NACC%d,%s,bw%d%s>", CH, S16 ? "u16" : "u8", Q, PX, TX, P, NACC,
-             p.fma ? "fma" : "exact", bw, work_suffix(p.work));
+    if (p.fma) resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true, RC><<<grid, 64 * bw, lds, s>>>(p);
+    else resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false, RC><<<grid, 64 * bw, lds, s>>>(p);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_run<ch%d,%s,Q%d,PX%d,TX%d,P%d,NACC%d,%s,bw%d%s%s>", CH, S16 ? "u16" : "u8", Q, PX, TX, P, NACC,
+             p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "", work_suffix(p.work));
     if (name) *name = g_kernel_name;
     return hipGetLastError();
 }
 
-// Instantiations per pixel format: X(Q, PX, TX, P) — period in outputs, period in source pixels, taps, outputs per lane; each
+// Instantiations per pixel format: X(Q, PX, TX, P, RC) — period in outputs, period in source pixels, taps, outputs per lane, window
+// offsets inside a period rounded down / up; each
 // with 4 and 6 pending output rows.  7.5x (15/2: a 4K frame to 512 columns): 21 taps with picha's default filter scale, 31
 // (30 + the half pixel) at filter scale 1, for every filter but box / triangle.  Survey over formats (r03, 128 x 4K -> 512x288,
 // profiles/r03_survey_run_kernel.txt): grey 31 taps -13 % against the row-staged kernel (fma -20 %), greya 31 taps -35 % (two
@@ -392,8 +394,8 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // the accumulator kernel's row list serves it, capi.cpp get_yrows.)
 #define PICHA_RUN_LIST_0(X) /* rgb */
 #define PICHA_RUN_LIST_1(X) /* rgba */
-#define PICHA_RUN_LIST_2(X) /* grey */ X(1, 6, 17, 4) X(1, 8, 23, 4) X(1, 8, 23, 8) X(2, 15, 21, 2) X(2, 15, 21, 4) X(2, 15, 21, 8) X(2, 15, 31, 2) X(2, 15, 31, 4)
-#define PICHA_RUN_LIST_3(X) /* greya */ X(2, 15, 21, 2) X(2, 15, 31, 2) X(2, 15, 31, 4)
+#define PICHA_RUN_LIST_2(X) /* grey */ X(1, 6, 17, 4, 0) X(1, 8, 23, 4, 0) X(1, 8, 23, 8, 0) X(2, 15, 21, 2, 0) X(2, 15, 21, 4, 0) X(2, 15, 21, 8, 0) X(2, 15, 31, 2, 0) X(2, 15, 31, 4, 0) X(2, 15, 30, 4, 1)
+#define PICHA_RUN_LIST_3(X) /* greya */ X(2, 15, 21, 2, 0) X(2, 15, 31, 2, 0) X(2, 15, 31, 4, 0) X(2, 15, 30, 2, 1)
 #define PICHA_RUN_LIST_4(X) /* r16 */
 #define PICHA_RUN_LIST_5(X) /* r16g16 */
 #define PICHA_RUN_LIST_6(X) /* r16g16b16 */
@@ -408,9 +410,9 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #define PICHA_CAT(a, b) PICHA_CAT2(a, b)
 #define PICHA_RUN_LIST PICHA_CAT(PICHA_RUN_LIST_, PICHA_RUN_PIXEL)
 
-bool PICHA_CAT(run_supported_pixel, PICHA_RUN_PIXEL)(int q, int px, int tx, int per_lane, int nacc) {
+bool PICHA_CAT(run_supported_pixel, PICHA_RUN_PIXEL)(int q, int px, int tx, int per_lane, int nacc, int rc) {
     if (nacc != 4 && nacc != 6) return false;
-#define X(Q, PX, TX, P) if (q == Q && px == PX && tx == TX && per_lane == P) return true;
+#define X(Q, PX, TX, P, RC) if (q == Q && px == PX && tx == TX && per_lane == P && rc == RC) return true;
     PICHA_RUN_LIST(X)
 #undef X
     return false;
@@ -419,10 +421,10 @@ bool PICHA_CAT(run_supported_pixel, PICHA_RUN_PIXEL)(int q, int px, int tx, int 
 hipError_t PICHA_CAT(launch_run_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipStream_t s, const char **name) {
     [[maybe_unused]] constexpr int CH = pixel_channels(PICHA_RUN_PIXEL);
     [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
-#define X(Q, PX, TX, P)                                                                                   \
-    if (p.period == Q && p.period_px == PX && p.x_taps == TX && p.x_per_lane == P) {                      \
-        if (p.nacc == 4) return launch_run_t<CH, S16, Q, PX, TX, P, 4>(p, s, name);                       \
-        if (p.nacc == 6) return launch_run_t<CH, S16, Q, PX, TX, P, 6>(p, s, name);                       \
+#define X(Q, PX, TX, P, RC)                                                                               \
+    if (p.period == Q && p.period_px == PX && p.x_taps == TX && p.x_per_lane == P && p.off_ceil == RC) {  \
+        if (p.nacc == 4) return launch_run_t<CH, S16, Q, PX, TX, P, 4, RC>(p, s, name);                   \
+        if (p.nacc == 6) return launch_run_t<CH, S16, Q, PX, TX, P, 6, RC>(p, s, name);                   \
     }
     PICHA_RUN_LIST(X)
 #undef X
@@ -436,7 +438,7 @@ hipError_t PICHA_CAT(launch_edges_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hi
     dim3 grid((p.dst_h + p.edge_rows - 1) / p.edge_rows, 2, p.n_images);
     const size_t lds = sizeof(float) * kEdgeFloats;
     const int txe = (p.x_taps + 3) / 4 * 4;
-#define X(Q, PX, TX, P) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
+#define X(Q, PX, TX, P, RC) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
     PICHA_RUN_LIST(X)
 #undef X
     return hipErrorInvalidValue;

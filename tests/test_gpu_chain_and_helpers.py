@@ -7,6 +7,8 @@
 """
 import ctypes
 
+import re
+
 import numpy as np
 import pytest
 
@@ -237,9 +239,14 @@ def test_run_kernel_matches_oracle(case):
     img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 4, 8])))
     want = oracle_resize(img, dw, dh, filt, fscale)
     opts = {"width": dw, "height": dh, "filter": filt, "filterScale": fscale}
-    keys = (b"run", b"per_lane", b"row_chunks", b"work", b"numerics", b"block_waves")
+    keys = (b"run", b"per_lane", b"row_chunks", b"work", b"numerics", b"block_waves", b"run_round")
     try:
         N.check(N.lib().picha_hip_set_option(b"run", 1))
+        for rnd in ((1, 2) if taps == 31 else (0,)):   # both window-offset roundings where the table has the half-pixel step
+            N.check(N.lib().picha_hip_set_option(b"run_round", rnd))
+            got = picha.resizeSync(img, opts)
+            assert max_code_diff(got, want) == 0, (case, rnd, N.lib().picha_hip_last_kernel())
+        N.check(N.lib().picha_hip_set_option(b"run_round", 0))
         for per_lane in RUN_PER_LANE[(pixel, period, taps)]:
             for chunks, work in ((0, 0), (1, 3), (3, 1), (2, 2)):
                 N.check(N.lib().picha_hip_set_option(b"per_lane", per_lane))
@@ -247,7 +254,9 @@ def test_run_kernel_matches_oracle(case):
                 N.check(N.lib().picha_hip_set_option(b"work", work))
                 got = picha.resizeSync(img, opts)
                 name = N.lib().picha_hip_last_kernel().decode()
-                assert name.startswith("resize_run<ch%d,u8,Q%d,PX%d,TX%d,P%d," % (ch, period, period_px, taps, per_lane or (4 if ch == 1 else 2))), name
+                pl = per_lane or (4 if ch == 1 else 2)
+                # 31 taps: 30 with the window offsets rounded up (",ceil"), where that form is instantiated
+                assert re.match(r"resize_run<ch%d,u8,Q%d,PX%d,TX(%d|%d),P%d," % (ch, period, period_px, taps, taps - 1, pl), name), name
                 assert "+ resize_edges<" in name, name
                 assert max_code_diff(got, want) == 0, (case, per_lane, chunks, work, name)
         for k in keys[1:]:

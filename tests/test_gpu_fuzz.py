@@ -17,7 +17,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up", "run"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up", "run", "run_round"):
         set_opt(k, 0)
 
 
@@ -143,6 +143,7 @@ def test_random_half_integer_downscales_match_oracle(seed):
         numerics = int(rng.integers(0, 4) == 0)
         set_opt("numerics", numerics)
         set_opt("run", int(rng.choice([1, 1, 0])))
+        set_opt("run_round", int(rng.choice([0, 0, 1, 2])))
         set_opt("per_lane", int(rng.choice([0, 0, 2, 4, 8])))
         set_opt("row_chunks", int(rng.choice([0, 0, 1, 2, 5])))
         set_opt("work", int(rng.choice([0, 0, 1, 2, 3])))

@@ -644,7 +644,7 @@ def test_kernel_selection_for_the_baseline_workloads():
         ("r16", 2048, 64, 1024, 32, {"filter": "triangle"}, "resize_sym<ch1,u16,P4,SX2,TX3,SY2,TY3"),
         ("greya", 2304, 96, 768, 32, {}, "resize_sym<ch2,u8,P2,SX3,TX8,SY3,TY8"),
         ("rgba", 384, 216, 192, 108, {"filter": "cubic"}, "resize_stream<ch4,u8,P2,SX2,TX7,SY2,TY7"),     # cfg2, 7 taps
-        ("grey", 3840, 216, 512, 51, {"filter": "lanczos"}, "resize_run<ch1,u8,Q2,PX15,TX31,P4,NACC"),   # cfg3b (x: 7.5x = period 2 / 15 pixels, y: 4.2x): run kernel (r03; was the row-staged kernel)
+        ("grey", 3840, 216, 512, 51, {"filter": "lanczos"}, "resize_run<ch1,u8,Q2,PX15,TX30,P4,NACC"),   # cfg3b (x: 7.5x = period 2 / 15 pixels, y: 4.2x): run kernel (r03; was the row-staged kernel)
         ("grey", 3584, 216, 512, 51, {"filter": "lanczos"}, "resize_rows<src ch1u8,ch1,u8,P2,S7,TX32"),   # 7x, 28 taps: no run-kernel instantiation, the row-staged kernel
         ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_acc<ch4,u16,P2,S4,TX15,NACC4,exact,xch"),   # cfg5: neighbour-exchange accumulator kernel (r03)
         ("r16", 320, 180, 640, 360, {}, "resize_acc<ch1,u16,P4,S0,TX5,NACC6"),                           # 16-bit upscale: accumulator kernel, four outputs per lane (r03)
