@@ -156,6 +156,7 @@ struct DeviceAxis {
         int x_base = 0, taps = 0;
     };
     std::map<std::tuple<int, int, int, int>, RunTable> runtables;
+    int32_t *yrange = nullptr;  // y role of resize_up_kernel: [dst][2] {first source row needed by this or any later output row, last row so far}
 
     DeviceAxis() = default;
     DeviceAxis(const DeviceAxis &) = delete;
@@ -167,6 +168,7 @@ struct DeviceAxis {
         for (auto &kv : yrows) if (kv.second.blob) (void)hipFree(kv.second.blob);
         for (auto &kv : rows_strips) if (kv.second.blob) (void)hipFree(kv.second.blob);
         for (auto &kv : runtables) if (kv.second.blob) (void)hipFree(kv.second.blob);
+        if (yrange) (void)hipFree(yrange);
     }
     // fused, y role
     int4 *y_info = nullptr;
@@ -903,6 +905,23 @@ int get_rows_strips(DeviceCtx *ctx, DeviceAxis *ax, const DeviceAxis::XTable *xt
 long g_opt_fuse = 0;  // chained convert+resize: 0 auto (one fused kernel where it exists and was measured faster), 1 one kernel wherever it exists, 2 always two kernels
 long g_opt_rows = 0;  // row-staged (LDS) downscale kernel: 0 auto, 1 whenever it applies, 2 never
 
+// y role of resize_up_kernel (and of resize_edges_kernel behind it): the source rows a block of output rows needs
+int get_yrange(DeviceCtx *ctx, DeviceAxis *ay, const int32_t **out) {
+    std::lock_guard<std::mutex> lk(ctx->mu);
+    if (!ay->yrange) {
+        const AxisTaps &t = ay->host;
+        const int dst = t.dst_size;
+        std::vector<int32_t> range((size_t)dst * 2);
+        for (int y = 0; y < dst; ++y) { range[2 * y] = t.left[y]; range[2 * y + 1] = t.left[y] + t.count[y] - 1; }
+        for (int y = dst - 2; y >= 0; --y) range[2 * y] = std::min(range[2 * y], range[2 * (y + 1)]);
+        for (int y = 1; y < dst; ++y) range[2 * y + 1] = std::max(range[2 * y + 1], range[2 * (y - 1) + 1]);
+        HIP_TRY(hipMalloc((void **)&ay->yrange, range.size() * sizeof(int32_t)));
+        HIP_TRY(hipMemcpy(ay->yrange, range.data(), range.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    *out = ay->yrange;
+    return PICHA_OK;
+}
+
 long g_opt_run = 0;   // run kernel (periodic tap tables, kernels_run.hip): 0 auto, 1 whenever it applies, 2 never
 long g_opt_run_round = 0;  // its window offsets inside a period: 0 auto (the shorter window), 1 rounded down, 2 rounded up
 
@@ -920,7 +939,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         opt_bw = g_opt_block_waves;
     }
     if (opt_run == 2 || s0.pixel != d0.pixel) return PICHA_OK;
-    if (d0.width >= s0.width || d0.height >= s0.height) return PICHA_OK;  // downscales only
+    // downscales (the march + per-source-row records), or upscales by an integer factor in x (resize_up_kernel: register ring in y)
+    const bool up = d0.width > s0.width && d0.height > s0.height;
+    if (!up && (d0.width >= s0.width || d0.height >= s0.height)) return PICHA_OK;
+    if (up && (d0.width % s0.width != 0 || d0.width / s0.width > 4)) return PICHA_OK;
     const size_t src_span = image_span(s0), dst_span = image_span(d0);
     if (src_span >= (1u << 30) || dst_span >= (1u << 30)) return PICHA_OK;
     const int al = fused_align(pixel);
@@ -945,14 +967,30 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     const int wmode = fma ? 1 : exact_unpack_scaled(kChannels[pixel], is16 != 0) ? 2 : 0;
     // shape: the smallest instantiated tap count >= the table's, outputs per lane as instantiated ("per_lane" forces one)
     const DeviceAxis::YRows *yr = nullptr;
+    const int32_t *up_range = nullptr;
     int nacc = 0, per_lane = 0, ktaps = 0, ceil_off = 0;
-    for (int na : {4, 6}) {
-        const DeviceAxis::YRows *cand = nullptr;
-        rc = get_yrows(ctx, ay, na, &cand);
+    if (up) {
+        // vertical windows of at most four consecutive rows, each still in the four-row ring when its output row is summed
+        const AxisTaps &ty = ay->host;
+        int emitted = -1;   // last source row processed when output row y is emitted
+        for (int y = 0; y < d0.height; ++y) {
+            if (ty.count[y] < 1 || ty.count[y] > 4) return PICHA_OK;
+            for (int j = 0; j < ty.count[y]; ++j)
+                if (ty.eff[(size_t)y * ty.taps + j] != ty.left[y] + j) return PICHA_OK;
+            emitted = std::max(emitted, ty.left[y] + ty.count[y] - 1);
+            if (ty.left[y] <= emitted - 4) return PICHA_OK;
+        }
+        rc = get_yrange(ctx, ay, &up_range);
         if (rc) return rc;
-        if (cand->ok) { yr = cand; nacc = na; break; }
+    } else {
+        for (int na : {4, 6}) {
+            const DeviceAxis::YRows *cand = nullptr;
+            rc = get_yrows(ctx, ay, na, &cand);
+            if (rc) return rc;
+            if (cand->ok) { yr = cand; nacc = na; break; }
+        }
+        if (!yr) return PICHA_OK;
     }
-    if (!yr) return PICHA_OK;
     // window offsets inside a period rounded down or up (7.5x, 30 taps: 31 with the offsets 0 / 7, 30 with 0 / 8): the form with the
     // shorter window first; outputs per lane: four for single-channel pixels, two for the others (r03 survey,
     // profiles/r03_survey_run_kernel.txt)
@@ -960,13 +998,15 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     for (int c = 0; c < 2; ++c) tx_of[c] = run_table_taps(ax->host, period, period_px, c, &xb_unused);
     if (tx_of[0] <= 0) return PICHA_OK;
     static const int order1[] = {4, 8, 2}, order2[] = {2, 4, 8};
+    // upscales (r03, profiles/r03_ab_up_kernel.txt): the longest run that is instantiated
+    static const int order_up[] = {8, 4, 2};
     for (int k = 0; k < 2 && !per_lane; ++k) {
         const int c = (tx_of[1] > 0 && tx_of[1] < tx_of[0]) ? 1 - k : k;   // the shorter window first
         if (tx_of[c] <= 0 || (period == 1 && c == 1) || (opt_run_round != 0 && opt_run_round != c + 1)) continue;
         for (int tx = tx_of[c]; tx <= tx_of[c] + 3 && !per_lane; ++tx)
-            for (int pl : (kChannels[pixel] == 1 ? order1 : order2)) {
+            for (int pl : (up ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
                 if (opt_per_lane > 0 && pl != opt_per_lane) continue;
-                if (pl % period || !run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c)) continue;
+                if (pl % period || !(up ? up_kernel_supported(pixel, period, tx, pl, c) : run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c))) continue;
                 per_lane = pl; ktaps = tx; ceil_off = c;
                 break;
             }
@@ -975,7 +1015,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // where it is the default (same survey): windows of 26 taps and more (cfg3b: -3 % reference arithmetic, -10 % fma against the
     // row-staged kernel; greya -35 %); shorter windows only for batches that still fill the chip with a quarter of the
     // accumulator kernel's waves (256 x 4K -> 512x288 grey: -11 %; 128 images: a tie; integer scales 6x / 8x: -9 .. -13 % at 128 images)
-    if (opt_run == 0 && ktaps < 26 && !(kChannels[pixel] == 1 && n >= (period == 1 ? 96 : 192))) return PICHA_OK;
+    if (!up && opt_run == 0 && ktaps < 26 && !(kChannels[pixel] == 1 && n >= (period == 1 ? 96 : 192))) return PICHA_OK;
     const DeviceAxis::RunTable *rt = nullptr;
     rc = get_runtable(ctx, ax, period, period_px, ceil_off, ktaps, wmode, is16, &rt);
     if (rc) return rc;
@@ -1067,7 +1107,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     p.x_groups = x_groups;
     p.x_canon = rt->canon;
     p.fma = fma;
-    p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc;
+    if (up) { p.yrow_range = up_range; p.y_left = ay->left; }
+    else { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; }
     p.cx0 = rt->c0; p.cx1 = rt->c1;
     if (opt_run == 3) { p.cx0 = 0; p.cx1 = d0.width; }  // measurement only: no edge pass (the edge columns come out wrong)
     p.edge_rows = edge_rows;
@@ -1094,7 +1135,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         return fail(PICHA_ERR_HIP, "run-kernel resize launch failed: %s", hipGetErrorString(e));
     };
     // launch form: the plain grid (measured r03 on cfg3b: item list +3 %, persistent +30 %; the edge kernel follows either way)
-    const int work_mode = opt_work == 1 || opt_work == 2 ? (int)opt_work : 0;
+    const int work_mode = !up && (opt_work == 1 || opt_work == 2) ? (int)opt_work : 0;
     if (work_mode) {
         const DeviceCtx::ItemList *il = nullptr;
         rc = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(16, p.rows_per_chunk / (int)opt_work_tail_div), (int)opt_work_tail, &il);
@@ -1132,7 +1173,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
             if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
             else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
             q.stash_img0 = done;
-            hipError_t e = launch_resize_run_kernel(pixel, q, s, &g_last_kernel);
+            hipError_t e = up ? launch_resize_up_kernel(pixel, q, s, &g_last_kernel) : launch_resize_run_kernel(pixel, q, s, &g_last_kernel);
             if (e == hipSuccess) e = launch_resize_edges_kernel(pixel, q, s);
             if (e != hipSuccess) return fail_launch(e);
             done += m;

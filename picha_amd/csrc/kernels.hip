@@ -34,7 +34,9 @@ PICHA_DECL_SYM(4) PICHA_DECL_SYM(5) PICHA_DECL_SYM(6) PICHA_DECL_SYM(7)
 #define PICHA_DECL_RUN(N)                                                                \
     bool run_supported_pixel##N(int q, int px, int tx, int per_lane, int nacc, int rc);   \
     hipError_t launch_run_pixel##N(const RunParams &p, hipStream_t s, const char **name); \
-    hipError_t launch_edges_pixel##N(const RunParams &p, hipStream_t s);
+    hipError_t launch_edges_pixel##N(const RunParams &p, hipStream_t s); \
+    bool up_supported_pixel##N(int f, int tx, int per_lane, int rc); \
+    hipError_t launch_up_pixel##N(const RunParams &p, hipStream_t s, const char **name);
 PICHA_DECL_RUN(0) PICHA_DECL_RUN(1) PICHA_DECL_RUN(2) PICHA_DECL_RUN(3)
 PICHA_DECL_RUN(4) PICHA_DECL_RUN(5) PICHA_DECL_RUN(6) PICHA_DECL_RUN(7)
 #undef PICHA_DECL_RUN
@@ -49,6 +51,22 @@ bool run_kernel_supported(int pixel, int period, int period_px, int taps, int pe
 hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s, const char **name) {
     switch (pixel) {
 #define PICHA_CASE(N) case N: return launch_run_pixel##N(p, s, name);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return hipErrorInvalidValue;
+}
+bool up_kernel_supported(int pixel, int factor, int taps, int per_lane, int off_ceil) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return up_supported_pixel##N(factor, taps, per_lane, off_ceil);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return false;
+}
+hipError_t launch_resize_up_kernel(int pixel, const RunParams &p, hipStream_t s, const char **name) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return launch_up_pixel##N(p, s, name);
     PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
 #undef PICHA_CASE
     }

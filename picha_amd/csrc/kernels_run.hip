@@ -358,6 +358,206 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     }, run_item);
 }
 
+// ---------------------------------------------------------------------------------------------
+// Integer UPSCALES (r03): the same horizontal scheme — F outputs per source pixel repeat the tap table with period F (Q = F,
+// PX = 1), a lane resamples a run of P outputs from one tiny window with wave-uniform weights — and a vertical part made for
+// upscales: the last four resampled rows stay in REGISTERS (a ring indexed by row & 3; picha's upscale windows are at most
+// three rows for every filter but lanczos) and every output row whose window ends with the current source row is summed from
+// them, its taps in the reference's order (src/resize.cc:125-129), then packed and stored.  No LDS ring (the span kernel of
+// 5.2 reads count x P cells per output row and carries per-tap branches), no per-row records over NACC accumulators of which
+// half hold zeros (the accumulator form of 5.3c).  Edge columns as for the downscales: stash + resize_edges_kernel.
+// ---------------------------------------------------------------------------------------------
+template <int CH, bool S16, int F, int TX, int P, bool FMA, int RC>
+__global__ __launch_bounds__(256) void resize_up_kernel(RunParams p) {
+    using C = RunCfg<CH, S16, F, 1, TX, P, RC>;
+    static_assert(P % F == 0, "a lane owns whole periods");
+    constexpr int NRAW = C::NW;
+    constexpr int NB = 4;  // row buffers == ring length: one unrolled group of four rows
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+    const int bx = blockIdx.x, img = blockIdx.z;
+    const int y0 = blockIdx.y * p.rows_per_chunk, y1 = min(p.dst_h, y0 + p.rows_per_chunk);
+    const int grp0 = (bx * bw + wave) * kWave;
+    if (grp0 * P >= p.dst_w || y0 >= y1) return;
+    const int x0 = (grp0 + lane) * P;
+
+    const uint8_t *sbase = uniform_ptr(p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch);
+    uint8_t *dbase = uniform_ptr(p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch);
+    const int sadj = C::BROT ? int(reinterpret_cast<uintptr_t>(sbase) & 3u) : 0;
+    const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint8_t *>(sbase) - sadj, 0, C::WORDS ? p.src_bytes : ((p.src_bytes + sadj + 3u) & ~3u), 0x00020000);
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
+
+    const_i32_ptr xc = (const_i32_ptr)(p.x_canon);
+    int32_t wbits[F * TX];
+#pragma unroll
+    for (int j = 0; j < F * TX; ++j) wbits[j] = xc[j];
+    float wx[F][TX];
+#pragma unroll
+    for (int q = 0; q < F; ++q)
+#pragma unroll
+        for (int j = 0; j < TX; ++j) asm("v_mov_b32 %0, %1" : "=v"(wx[q][j]) : "s"(wbits[q * TX + j]));
+    const int32_t lane_off = (p.x_base + (grp0 + lane) * (P / F)) * C::BPP + sadj;
+    const bool careful = __any(lane_off < 0);
+
+    const_i32_ptr yrange = (const_i32_ptr)(p.yrow_range);
+    const_i32_ptr yleft = (const_i32_ptr)(p.y_left), ycount = (const_i32_ptr)(p.y_count), ywgt = (const_i32_ptr)(p.y_weight);
+    const int r0 = yrange[2 * y0], r1 = yrange[2 * (y1 - 1) + 1];
+
+    // stash of the edge lanes' raw rows (see resize_run_kernel)
+    extern __shared__ __attribute__((aligned(16))) uint32_t stash_lds[];
+    constexpr int NRP = (NRAW + 3) / 4 * 4;
+    const int g_last = (p.dst_w - 1) / P;
+    const int st_side_lane = p.stash == nullptr ? -1 : (grp0 + lane == 0) ? 0 : (grp0 + lane == g_last) ? 1 : -1;
+    const bool st_has0 = __any(st_side_lane == 0), st_has1 = __any(st_side_lane == 1);
+    const bool st_wave = st_has0 || st_has1;
+    uint32_t *st_buf = stash_lds + wave * (2 * kWave * NRP);
+    const unsigned st_stride = unsigned(p.stash_words) * 4u, st_bytes = st_stride * unsigned(p.src_h);
+    const __amdgpu_buffer_rsrc_t stash_rs = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<uint8_t *>(p.stash) + (size_t)(p.stash_img0 + img) * 2 * st_bytes, 0, p.stash ? 2 * st_bytes : 0, 0x00020000);
+    auto stash_row = [&](uint32_t (&cur)[NRAW], int row) __attribute__((always_inline)) {
+        const int slot = (row - r0) & (kWave - 1);
+        if (st_side_lane >= 0) {
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k) st_buf[(st_side_lane * kWave + slot) * NRP + k] = cur[k];
+        }
+        if (slot == kWave - 1 || row == r1) {  // wave-uniform: flush rows [row - slot, row]
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int side = 0; side < 2; ++side) {
+                if (side == 0 ? st_has0 : st_has1) {
+                    if (lane <= slot) {
+                        uint32_t t[NRAW];
+#pragma unroll
+                        for (int k = 0; k < NRAW; ++k) t[k] = st_buf[(side * kWave + lane) * NRP + k];
+                        store_dwords<NRAW>(stash_rs, uint32_t(side) * st_bytes + uint32_t(row - slot + lane) * st_stride, t);
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    };
+
+    uint32_t raw[NB][NRAW];
+#pragma unroll
+    for (int k = 0; k < NB - 1; ++k) {
+        const int row = min(r0 + k, r1);
+        const int32_t off = row * p.src_stride + lane_off;
+        if (careful && row <= 0) load_span<C, true>(src_rs, off, raw[k]);
+        else load_span<C, false>(src_rs, off, raw[k]);
+    }
+
+    float ring[4][P][CH];   // resampled rows, slot = row & 3
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) ring[a][q][c] = 0.0f;
+
+    // the next output row to emit and its window, fetched ahead through the scalar cache
+    int y = y0;
+    int yl = yleft[y0], yc = ycount[y0];
+    int wb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) wb[j] = ywgt[(size_t)y0 * p.y_taps + min(j, p.y_taps - 1)];
+
+    auto emit = [&](auto base_c) __attribute__((always_inline)) {
+        constexpr int B = decltype(base_c)::value;   // ring slot of the window's first row
+        float o[P][CH];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (j < yc) {   // wave-uniform
+                float w;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(w) : "s"(wb[j]));
+#pragma unroll
+                for (int q = 0; q < P; ++q)
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const float v = ring[(B + j) & 3][q][c];
+                        if (j == 0) o[q][c] = w * v;
+                        else if constexpr (FMA) o[q][c] = __builtin_fmaf(w, v, o[q][c]);
+                        else o[q][c] = o[q][c] + w * v;
+                    }
+            }
+        }
+        store_lane_outputs<C, CH, S16, P, FMA>(o, dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
+    };
+
+    auto process_row = [&](uint32_t (&cur)[NRAW], int row, auto slot_c) __attribute__((always_inline)) {
+        constexpr int SL = decltype(slot_c)::value;   // == (row - r0 + (r0 & 3)) & 3, i.e. row & 3 with the unroll phase folded in
+        if (st_wave && row <= r1) stash_row(cur, row);
+        // ---- horizontal pass (src/resize.cc:110-117) ----
+        uint32_t win[C::BROT ? C::NWIN : 1];
+        if constexpr (C::BROT) rotate_span<C>(cur, uint32_t(min(row, r1) * p.src_stride + lane_off) & 3u, win);
+        float h[P][CH];
+#pragma unroll
+        for (int q = 0; q < C::SPAN; ++q) {
+            float u[CH];
+            if constexpr (C::BROT) unpack_span_px<C, CH, S16, FMA>(win, q, u);
+            else unpack_span_px<C, CH, S16, FMA>(cur, q, u);
+#pragma unroll
+            for (int o = 0; o < P; ++o) {
+                const int j = q - run_off(F, 1, o, RC);
+                if (j >= 0 && j < TX) {
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        if (j == 0) h[o][c] = wx[o % F][0] * u[c];
+                        else if constexpr (FMA) h[o][c] = __builtin_fmaf(wx[o % F][j], u[c], h[o][c]);
+                        else h[o][c] = h[o][c] + wx[o % F][j] * u[c];
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < P; ++q)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) ring[SL][q][c] = h[q][c];
+        // ---- every output row whose window ends here (src/resize.cc:121-132) ----
+        while (y < y1 && yl + yc - 1 <= row) {   // wave-uniform
+            switch ((yl - r0) & 3) {               // ring slot of the window's first row: the ring is indexed by row - r0
+            case 0: emit(std::integral_constant<int, 0>{}); break;
+            case 1: emit(std::integral_constant<int, 1>{}); break;
+            case 2: emit(std::integral_constant<int, 2>{}); break;
+            default: emit(std::integral_constant<int, 3>{}); break;
+            }
+            ++y;
+            const int yn = min(y, p.dst_h - 1);
+            yl = yleft[yn]; yc = ycount[yn];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) wb[j] = ywgt[(size_t)yn * p.y_taps + min(j, p.y_taps - 1)];
+        }
+    };
+    // The unrolled group starts at r0, so position k of a group is ring slot (row - r0) & 3
+    auto step = [&](int r, auto k_c) __attribute__((always_inline)) {
+        constexpr int K = decltype(k_c)::value;
+        load_span<C, false>(src_rs, max(1, min(r + K + NB - 1, r1)) * p.src_stride + lane_off, raw[(K + NB - 1) % NB]);
+        if (r + K <= r1) process_row(raw[K], r + K, k_c);
+    };
+    for (int r = r0; r <= r1; r += NB) {
+        step(r, std::integral_constant<int, 0>{});
+        step(r, std::integral_constant<int, 1>{});
+        step(r, std::integral_constant<int, 2>{});
+        step(r, std::integral_constant<int, 3>{});
+    }
+}
+
+template <int CH, bool S16, int F, int TX, int P, int RC>
+hipError_t launch_up_t(const RunParams &p, hipStream_t s, const char **name) {
+    const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 4;
+    const size_t lds = p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, F, 1, TX, P, RC>::NW + 3) / 4 * 4) : 0;
+    dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
+    if (p.fma) resize_up_kernel<CH, S16, F, TX, P, true, RC><<<grid, 64 * bw, lds, s>>>(p);
+    else resize_up_kernel<CH, S16, F, TX, P, false, RC><<<grid, 64 * bw, lds, s>>>(p);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_up<ch%d,%s,F%d,TX%d,P%d,%s,bw%d%s>", CH, S16 ? "u16" : "u8", F, TX, P, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "");
+    if (name) *name = g_kernel_name;
+    return hipGetLastError();
+}
+
 template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC, int RC>
 hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
     const void *k = p.fma ? reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true, RC>)
@@ -401,6 +601,17 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #define PICHA_RUN_LIST_6(X) /* r16g16b16 */
 #define PICHA_RUN_LIST_7(X) /* r16g16b16a16 */
 
+// Upscale instantiations: U(F, TX, P, RC) — integer factor, taps, outputs per lane, window offsets inside a period rounded down / up
+// (2x with picha's defaults: 3 taps with the offsets rounded up; 4-tap filters: rounded down)
+#define PICHA_UP_LIST_0(U) /* rgb */ U(2, 3, 4, 1) U(2, 4, 4, 0)
+#define PICHA_UP_LIST_1(U) /* rgba */ U(2, 3, 2, 1) U(2, 3, 4, 1) U(2, 4, 2, 0) U(2, 4, 4, 0)
+#define PICHA_UP_LIST_2(U) /* grey */ U(2, 3, 4, 1) U(2, 3, 8, 1) U(2, 4, 4, 0) U(2, 4, 8, 0)
+#define PICHA_UP_LIST_3(U) /* greya */ U(2, 3, 4, 1) U(2, 3, 8, 1) U(2, 4, 4, 0) U(2, 4, 8, 0)
+#define PICHA_UP_LIST_4(U) /* r16 */ U(2, 3, 4, 1) U(2, 3, 8, 1) U(2, 4, 4, 0)
+#define PICHA_UP_LIST_5(U) /* r16g16 */ U(2, 3, 2, 1) U(2, 3, 4, 1) U(2, 4, 4, 0)
+#define PICHA_UP_LIST_6(U) /* r16g16b16 */ U(2, 3, 2, 1) U(2, 3, 4, 1) U(2, 4, 2, 0)
+#define PICHA_UP_LIST_7(U) /* r16g16b16a16 */ U(2, 3, 2, 1) U(2, 4, 2, 0)
+
 }  // namespace
 
 #ifndef PICHA_RUN_PIXEL
@@ -409,6 +620,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #define PICHA_CAT2(a, b) a##b
 #define PICHA_CAT(a, b) PICHA_CAT2(a, b)
 #define PICHA_RUN_LIST PICHA_CAT(PICHA_RUN_LIST_, PICHA_RUN_PIXEL)
+#define PICHA_UP_LIST PICHA_CAT(PICHA_UP_LIST_, PICHA_RUN_PIXEL)
 
 bool PICHA_CAT(run_supported_pixel, PICHA_RUN_PIXEL)(int q, int px, int tx, int per_lane, int nacc, int rc) {
     if (nacc != 4 && nacc != 6) return false;
@@ -431,16 +643,35 @@ hipError_t PICHA_CAT(launch_run_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipS
     return hipErrorInvalidValue;
 }
 
+bool PICHA_CAT(up_supported_pixel, PICHA_RUN_PIXEL)(int f, int tx, int per_lane, int rc) {
+#define U(F, TX, P, RC) if (f == F && tx == TX && per_lane == P && rc == RC) return true;
+    PICHA_UP_LIST(U)
+#undef U
+    return false;
+}
+
+hipError_t PICHA_CAT(launch_up_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipStream_t s, const char **name) {
+    [[maybe_unused]] constexpr int CH = pixel_channels(PICHA_RUN_PIXEL);
+    [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
+#define U(F, TX, P, RC) if (p.period == F && p.x_taps == TX && p.x_per_lane == P && p.off_ceil == RC) return launch_up_t<CH, S16, F, TX, P, RC>(p, s, name);
+    PICHA_UP_LIST(U)
+#undef U
+    return hipErrorInvalidValue;
+}
+
 hipError_t PICHA_CAT(launch_edges_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipStream_t s) {
     [[maybe_unused]] constexpr int CH = pixel_channels(PICHA_RUN_PIXEL);
     [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
     if (!p.stash) return hipSuccess;
-    dim3 grid((p.dst_h + p.edge_rows - 1) / p.edge_rows, 2, p.n_images);
-    const size_t lds = sizeof(float) * kEdgeFloats;
-    const int txe = (p.x_taps + 3) / 4 * 4;
+    [[maybe_unused]] dim3 grid((p.dst_h + p.edge_rows - 1) / p.edge_rows, 2, p.n_images);
+    [[maybe_unused]] const size_t lds = sizeof(float) * kEdgeFloats;
+    [[maybe_unused]] const int txe = (p.x_taps + 3) / 4 * 4;
 #define X(Q, PX, TX, P, RC) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
     PICHA_RUN_LIST(X)
 #undef X
+#define U(F, TX, P, RC) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
+    PICHA_UP_LIST(U)
+#undef U
     return hipErrorInvalidValue;
 }
 

@@ -288,6 +288,43 @@ def test_run_kernel_matches_oracle(case):
             N.check(N.lib().picha_hip_set_option(k, 0))
 
 
+@pytest.mark.parametrize("pixel", PIXELS)
+def test_integer_upscale_kernel_matches_oracle(pixel):
+    """r03: resize_up_kernel (kernels_run.hip) — 2x upscales in x with wave-uniform weights and a run of outputs per lane, the last
+    four resampled rows in registers, edge columns from the stash by resize_edges_kernel — against the oracle: the filters with
+    3- and 4-tap windows, vertical factors 2x / 2.5x / 3.1x, run lengths, row chunkings, padded strides, both numerics; run = 2
+    gives the kernels it replaces."""
+    rng = np.random.default_rng(5200 + PIXELS.index(pixel))
+    served = 0
+    for (sw, sh, dw, dh, filt, fscale) in [(96, 40, 192, 80, "cubic", 0.70), (160, 30, 320, 75, "cubic", 0.70), (130, 33, 260, 103, "cubic", 1.0),
+                                           (300, 20, 600, 40, "mitchel", 1.0), (64, 64, 128, 200, "triangle", 1.0), (200, 25, 400, 50, "catmulrom", 1.0),
+                                           (96, 40, 192, 80, "lanczos", 1.0), (96, 40, 192, 80, "box", 1.0)]:
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8])), edge_values=bool(rng.integers(0, 3) == 0))
+        want = oracle_resize(img, dw, dh, filt, fscale)
+        opts = {"width": dw, "height": dh, "filter": filt, "filterScale": fscale}
+        try:
+            for run, per_lane, chunks in ((1, 0, 0), (1, 2, 1), (1, 4, 3), (1, 8, 2), (0, 0, 0), (2, 0, 0)):
+                N.check(N.lib().picha_hip_set_option(b"run", run))
+                N.check(N.lib().picha_hip_set_option(b"per_lane", per_lane))
+                N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
+                got = picha.resizeSync(img, opts)
+                name = N.lib().picha_hip_last_kernel().decode()
+                served += name.startswith("resize_up<")
+                assert not (run == 2 and name.startswith("resize_up<")), name
+                assert max_code_diff(got, want) == 0, (pixel, sw, sh, dw, dh, filt, fscale, run, per_lane, chunks, name)
+            N.check(N.lib().picha_hip_set_option(b"run", 1))
+            N.check(N.lib().picha_hip_set_option(b"per_lane", 0))
+            N.check(N.lib().picha_hip_set_option(b"numerics", 1))
+            got = picha.resizeSync(img, opts)
+            assert max_code_diff(got, want) <= 1, (pixel, sw, filt, "fma", N.lib().picha_hip_last_kernel())
+        finally:
+            for k in (b"run", b"per_lane", b"row_chunks", b"numerics"):
+                N.check(N.lib().picha_hip_set_option(k, 0))
+    # (r16g16b16a16: only two outputs per lane are instantiated, and the three clipped columns at the right edge do not fit one lane:
+    #  the accumulator form keeps serving it)
+    assert served >= (0 if pixel == "r16g16b16a16" else 8), served
+
+
 def test_run_kernel_is_the_planners_choice_only_where_it_was_measured_faster():
     """Default options: long windows (>= 26 taps) of grey / greya at a periodic scale take the run kernel; 21-tap windows only
     for large grey batches; other formats, non-periodic scales and a forced row-staged kernel never."""
