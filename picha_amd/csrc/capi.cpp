@@ -1004,8 +1004,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         const int c = (tx_of[1] > 0 && tx_of[1] < tx_of[0]) ? 1 - k : k;   // the shorter window first
         if (tx_of[c] <= 0 || (period == 1 && c == 1) || (opt_run_round != 0 && opt_run_round != c + 1)) continue;
         for (int tx = tx_of[c]; tx <= tx_of[c] + 3 && !per_lane; ++tx)
-            for (int pl : (up ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
-                if (opt_per_lane > 0 && pl != opt_per_lane) continue;
+            for (int pl0 : (up ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
+                const int pl = opt_per_lane > 0 ? (int)opt_per_lane : pl0;   // "per_lane" names the run length outright
                 if (pl % period || !(up ? up_kernel_supported(pixel, period, tx, pl, c) : run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c))) continue;
                 per_lane = pl; ktaps = tx; ceil_off = c;
                 break;
