@@ -152,7 +152,8 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "rows"       row-staged LDS downscale kernel: 0 = auto, 1 = whenever it applies, 2 = never
  *   "run"        run kernel (scale = a ratio of small integers, e.g. 7.5: a lane resamples a run of consecutive outputs
  *                with wave-uniform weights; the edge columns come from a second small kernel) and its upscale form
- *                (resize_up: exactly 2x in x, vertical windows of at most four rows): 0 = auto (downscales: grey / greya
+ *                (resize_up: exactly 2x / 4x in x, vertical windows of at most four rows) and ring-aliased form (resize_ring:
+ *                lanczos at 2x / 4x): 0 = auto (downscales: grey / greya
  *                with >= 26 taps, shorter grey windows for batches of >= 192 images; 2x upscales: every format with an
  *                instantiation), 1 = wherever an instantiation exists, 2 = never.  "per_lane" (2, 4, 8), "row_chunks", "block_waves" and "work" (1, 2; default
  *                plain grid) apply to it too
@@ -182,7 +183,8 @@ long picha_hip_get_option(const char *key);
  *   "resize_acc<...>"        accumulator kernel ("P2": two outputs per lane, ",xch"; "S0": upscale shape, outputs share one
  *                            window; ",epilogue -> fmt": colour convert fused in at the store), "resize_acc_long<...>" (> 36 taps)
  *   "resize_rows<...>"       row-staged LDS kernel ("src chN -> chM": colour convert fused in)
- *   "resize_up<...> + resize_edges<N columns>"    2x upscale kernel (F: factor, P outputs per lane) and the edge-column kernel
+ *   "resize_up<...> / resize_ring<...> + resize_edges<N columns>"   ring-in-registers kernel: 2x / 4x upscales (F: factor, P outputs
+ *                            per lane) / ring-aliased lanczos downscales (K ring rows), and the edge-column kernel
  *   "resize_run<...> + resize_edges<N columns>"   run kernel (Q outputs / PX source pixels per period, P outputs per lane)
  *                            and the kernel that recomputes the N columns whose windows an image edge clips
  *   "resize_span<...>"       LDS-ring span kernel (upscales, ring-aliasing cases)

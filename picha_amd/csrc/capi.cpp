@@ -912,7 +912,8 @@ int get_yrange(DeviceCtx *ctx, DeviceAxis *ay, const int32_t **out) {
         const AxisTaps &t = ay->host;
         const int dst = t.dst_size;
         std::vector<int32_t> range((size_t)dst * 2);
-        for (int y = 0; y < dst; ++y) { range[2 * y] = t.left[y]; range[2 * y + 1] = t.left[y] + t.count[y] - 1; }
+        // (last row: the one the reference has resampled when it produces the output row, need[] >= the window's last row)
+        for (int y = 0; y < dst; ++y) { range[2 * y] = t.left[y]; range[2 * y + 1] = std::max(t.need[y], t.left[y] + t.count[y] - 1); }
         for (int y = dst - 2; y >= 0; --y) range[2 * y] = std::min(range[2 * y], range[2 * (y + 1)]);
         for (int y = 1; y < dst; ++y) range[2 * y + 1] = std::max(range[2 * y + 1], range[2 * (y - 1) + 1]);
         HIP_TRY(hipMalloc((void **)&ay->yrange, range.size() * sizeof(int32_t)));
@@ -969,28 +970,35 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     const DeviceAxis::YRows *yr = nullptr;
     const int32_t *up_range = nullptr;
     int nacc = 0, per_lane = 0, ktaps = 0, ceil_off = 0;
-    if (up) {
-        // vertical windows of at most four consecutive rows, each still in the four-row ring when its output row is summed
-        const AxisTaps &ty = ay->host;
-        int emitted = -1;   // last source row processed when output row y is emitted
-        for (int y = 0; y < d0.height; ++y) {
-            if (ty.count[y] < 1 || ty.count[y] > 4) return PICHA_OK;
-            for (int j = 0; j < ty.count[y]; ++j)
-                if (ty.eff[(size_t)y * ty.taps + j] != ty.left[y] + j) return PICHA_OK;
-            emitted = std::max(emitted, ty.left[y] + ty.count[y] - 1);
-            if (ty.left[y] <= emitted - 4) return PICHA_OK;
-        }
-        rc = get_yrange(ctx, ay, &up_range);
-        if (rc) return rc;
-    } else {
+    // Three vertical schemes: the march with per-source-row records (downscales without ring aliasing); the ring-in-registers kernel
+    // for upscales (ring of four rows) and for ring-aliased downscales whose reference ring is 8 or 16 rows (lanczos at 2x / 4x).
+    // The register ring reproduces the reference's ring whenever it has the reference's length, or the table has no aliasing and
+    // no output row needs more rows than the ring holds (taps.cpp: eff[] = the last row <= need[] in the tap's residue class).
+    int ring_rows = 0;
+    if (!up) {
         for (int na : {4, 6}) {
             const DeviceAxis::YRows *cand = nullptr;
             rc = get_yrows(ctx, ay, na, &cand);
             if (rc) return rc;
             if (cand->ok) { yr = cand; nacc = na; break; }
         }
-        if (!yr) return PICHA_OK;
     }
+    if (!yr) {
+        const AxisTaps &ty = ay->host;
+        bool aliased = false;
+        for (int y = 0; y < d0.height && !aliased; ++y)
+            for (int j = 0; j < ty.count[y]; ++j)
+                if (ty.eff[(size_t)y * ty.taps + j] != ty.left[y] + j) { aliased = true; break; }
+        if (up) ring_rows = 4;
+        else if (ty.ref_ring == 8 || ty.ref_ring == 16) ring_rows = ty.ref_ring;
+        else return PICHA_OK;
+        if (!(ring_rows == ty.ref_ring || (!aliased && ty.span <= ring_rows)) || ty.taps > ring_rows + 1) return PICHA_OK;
+        for (int y = 1; y < d0.height; ++y)
+            if (ty.need[y] < ty.need[y - 1]) return PICHA_OK;   // rows are emitted in order
+        rc = get_yrange(ctx, ay, &up_range);
+        if (rc) return rc;
+    }
+    const bool ring_mode = ring_rows > 0;
     // window offsets inside a period rounded down or up (7.5x, 30 taps: 31 with the offsets 0 / 7, 30 with 0 / 8): the form with the
     // shorter window first; outputs per lane: four for single-channel pixels, two for the others (r03 survey,
     // profiles/r03_survey_run_kernel.txt)
@@ -1006,7 +1014,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         for (int tx = tx_of[c]; tx <= tx_of[c] + 3 && !per_lane; ++tx)
             for (int pl0 : (up ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
                 const int pl = opt_per_lane > 0 ? (int)opt_per_lane : pl0;   // "per_lane" names the run length outright
-                if (pl % period || !(up ? up_kernel_supported(pixel, period, tx, pl, c) : run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c))) continue;
+                if (pl % period || !(ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c))) continue;
                 per_lane = pl; ktaps = tx; ceil_off = c;
                 break;
             }
@@ -1015,7 +1023,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // where it is the default (same survey): windows of 26 taps and more (cfg3b: -3 % reference arithmetic, -10 % fma against the
     // row-staged kernel; greya -35 %); shorter windows only for batches that still fill the chip with a quarter of the
     // accumulator kernel's waves (256 x 4K -> 512x288 grey: -11 %; 128 images: a tie; integer scales 6x / 8x: -9 .. -13 % at 128 images)
-    if (!up && opt_run == 0 && ktaps < 26 && !(kChannels[pixel] == 1 && n >= (period == 1 ? 96 : 192))) return PICHA_OK;
+    if (!ring_mode && opt_run == 0 && ktaps < 26 && !(kChannels[pixel] == 1 && n >= (period == 1 ? 96 : 192))) return PICHA_OK;
     const DeviceAxis::RunTable *rt = nullptr;
     rc = get_runtable(ctx, ax, period, period_px, ceil_off, ktaps, wmode, is16, &rt);
     if (rc) return rc;
@@ -1055,7 +1063,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         // (first row needed by the block's first output row or any later one .. last row needed so far)
         const AxisTaps &ty = ay->host;
         std::vector<int> first(d0.height), last(d0.height);
-        for (int y = 0; y < d0.height; ++y) { first[y] = ty.left[y]; last[y] = ty.left[y] + ty.count[y] - 1; }
+        for (int y = 0; y < d0.height; ++y) { first[y] = ty.left[y]; last[y] = std::max(ty.need[y], ty.left[y] + ty.count[y] - 1); }
         for (int y = d0.height - 2; y >= 0; --y) first[y] = std::min(first[y], first[y + 1]);
         for (int y = 1; y < d0.height; ++y) last[y] = std::max(last[y], last[y - 1]);
         auto max_rows = [&](int rows) {
@@ -1107,7 +1115,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     p.x_groups = x_groups;
     p.x_canon = rt->canon;
     p.fma = fma;
-    if (up) { p.yrow_range = up_range; p.y_left = ay->left; }
+    if (ring_mode) { p.yrow_range = up_range; p.y_left = ay->left; p.y_info = ay->y_info; p.ring_rows = ring_rows; }
     else { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; }
     p.cx0 = rt->c0; p.cx1 = rt->c1;
     if (opt_run == 3) { p.cx0 = 0; p.cx1 = d0.width; }  // measurement only: no edge pass (the edge columns come out wrong)
@@ -1135,7 +1143,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         return fail(PICHA_ERR_HIP, "run-kernel resize launch failed: %s", hipGetErrorString(e));
     };
     // launch form: the plain grid (measured r03 on cfg3b: item list +3 %, persistent +30 %; the edge kernel follows either way)
-    const int work_mode = !up && (opt_work == 1 || opt_work == 2) ? (int)opt_work : 0;
+    const int work_mode = !ring_mode && (opt_work == 1 || opt_work == 2) ? (int)opt_work : 0;
     if (work_mode) {
         const DeviceCtx::ItemList *il = nullptr;
         rc = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(16, p.rows_per_chunk / (int)opt_work_tail_div), (int)opt_work_tail, &il);
@@ -1173,7 +1181,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
             if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
             else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
             q.stash_img0 = done;
-            hipError_t e = up ? launch_resize_up_kernel(pixel, q, s, &g_last_kernel) : launch_resize_run_kernel(pixel, q, s, &g_last_kernel);
+            hipError_t e = ring_mode ? launch_resize_up_kernel(pixel, q, s, &g_last_kernel) : launch_resize_run_kernel(pixel, q, s, &g_last_kernel);
             if (e == hipSuccess) e = launch_resize_edges_kernel(pixel, q, s);
             if (e != hipSuccess) return fail_launch(e);
             done += m;

@@ -263,13 +263,15 @@ struct RunParams {
     const int32_t *y_count, *y_eff;
     const float *y_weight;  // [dst_h][y_taps]
     int y_taps;
-    const int32_t *y_left;  // [dst_h] (resize_up_kernel)
+    const int32_t *y_left;  // [dst_h] (resize_ring_kernel)
+    const int4 *y_info;     // [dst_h] {., need, ., .}: the last source row the reference has resampled when it produces the row
+    int ring_rows;          // resize_ring_kernel: rows of its register ring (the reference's ring where the table is aliased)
 };
 bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc, int off_ceil);
 hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s, const char **kernel_name);
-// integer upscales (period = the factor, period_px = 1): the last four resampled rows in registers, no accumulator records
-// (yrow_rec unused; yrow_range: per output row {first source row needed by it or any later row, last row so far})
-bool up_kernel_supported(int pixel, int factor, int taps, int per_lane, int off_ceil);
+// ring-in-registers kernel (integer upscales: period = the factor, period_px = 1, ring 4; ring-aliased downscales: ring = the
+// reference's): yrow_rec unused; yrow_range: per output row {first source row needed by it or any later row, last row so far}
+bool up_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int off_ceil, int ring_rows, int y_taps);
 hipError_t launch_resize_up_kernel(int pixel, const RunParams &p, hipStream_t s, const char **kernel_name);
 hipError_t launch_resize_edges_kernel(int pixel, const RunParams &p, hipStream_t s);  // after the run kernel, same stream: the columns outside [cx0, cx1)
 int run_kernel_resident_blocks(int pixel, const RunParams &p);

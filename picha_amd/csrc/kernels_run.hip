@@ -55,8 +55,7 @@ template <int CH, bool S16, int TXE> struct EdgeCfg {
 };
 
 // Edge columns [xa0, xa0 + na) of one side of one image for the output rows [y0, y1), by one wave; the reference's double sum
-// (src/resize.cc:110-117 into a zeroed row, :125-129 over the window's rows; the y tables of this kernel have no ring aliasing,
-// so those are rows left .. left + count - 1) with the columns' own weights from the generic tables, reference arithmetic in
+// (src/resize.cc:110-117 into a zeroed row, :125-129 over the rows the ring holds for the window's taps: y_eff) with the columns' own weights from the generic tables, reference arithmetic in
 // both numerics flavours.  The source pixels come from the STASH the march wrote: per (image, side, source row) the NRAW raw
 // dwords of the lane that holds the side's edge columns (stash_rs describes this image-side's rows, st_stride bytes apart; the
 // side's lane window starts st_org bytes into the image row, a multiple of 4, possibly negative).  Through kEdgeFloats floats of LDS:
@@ -93,7 +92,8 @@ __device__ __forceinline__ void edge_pass(const RunParams &p, __amdgpu_buffer_rs
 #pragma unroll 8
         for (int i = lane; i < rows * p.y_taps; i += kWave) lds_wy[i] = p.y_weight[(size_t)ya * p.y_taps + i];
         const int yl = min(ya + lane, yb - 1);     // phase B's row of this lane (block rows <= 64)
-        const int ny_l = p.y_count[yl], left_l = p.y_eff[(size_t)yl * p.y_taps];
+        const int ny_l = p.y_count[yl];
+        const int32_t *eff_l = p.y_eff + (size_t)yl * p.y_taps;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -147,7 +147,7 @@ __device__ __forceinline__ void edge_pass(const RunParams &p, __amdgpu_buffer_rs
             for (int ch = 0; ch < CH; ++ch) acc[ch] = 0.0f;
             for (int j = 0; j < ny_max; ++j) {
                 const float wj = j < ny_l ? lds_wy[(yl - ya) * p.y_taps + j] : 0.0f;
-                const int sr = min(max(left_l + min(j, ny_l - 1) - ra, 0), nsr - 1);
+                const int sr = min(max(eff_l[min(j, ny_l - 1)] - ra, 0), nsr - 1);   // (the row the reference's ring holds for this tap)
 #pragma unroll
                 for (int ch = 0; ch < CH; ++ch) acc[ch] = acc[ch] + wj * lds_h[(c * nsr + sr) * CH + ch];
             }
@@ -358,21 +358,36 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     }, run_item);
 }
 
+// compile-time helpers of resize_ring_kernel: call f(integral_constant<i>) for the run-time i in [0, N) / for every i in [0, N)
+template <int N, int I = 0, typename Fn> __device__ __forceinline__ void switch_slot(int i, Fn &&f) {
+    if constexpr (I + 1 == N) { f(std::integral_constant<int, I>{}); }
+    else { if (i == I) f(std::integral_constant<int, I>{}); else switch_slot<N, I + 1>(i, f); }
+}
+template <int N, int I = 0, typename Fn> __device__ __forceinline__ void unroll_steps(int r, Fn &&f) {
+    if constexpr (I < N) { f(r, std::integral_constant<int, I>{}); unroll_steps<N, I + 1>(r, f); }
+}
+
 // ---------------------------------------------------------------------------------------------
-// Integer UPSCALES (r03): the same horizontal scheme — F outputs per source pixel repeat the tap table with period F (Q = F,
-// PX = 1), a lane resamples a run of P outputs from one tiny window with wave-uniform weights — and a vertical part made for
-// upscales: the last four resampled rows stay in REGISTERS (a ring indexed by row & 3; picha's upscale windows are at most
-// three rows for every filter but lanczos) and every output row whose window ends with the current source row is summed from
-// them, its taps in the reference's order (src/resize.cc:125-129), then packed and stored.  No LDS ring (the span kernel of
-// 5.2 reads count x P cells per output row and carries per-tap branches), no per-row records over NACC accumulators of which
-// half hold zeros (the accumulator form of 5.3c).  Edge columns as for the downscales: stash + resize_edges_kernel.
+// Ring-in-registers kernel (r03): the same horizontal scheme — a periodic tap table (Q outputs per PX source pixels), a lane
+// resamples a run of P outputs from one window with wave-uniform weights — and a vertical part that IS the reference's ring
+// (src/resize.cc:52-64,121-132): the last K resampled rows stay in REGISTERS, slot = row mod K, written at compile-time
+// positions of a loop unrolled over K rows, and every output row is summed from them as soon as the last row the reference has
+// resampled by then (its `need`, src/resize.cc:104) is in — taps in the reference's order, slot of tap j = (left + j) mod K.
+//   * integer UPSCALES (Q = factor, PX = 1, K = 4: picha's upscale windows are at most three rows, four for the 4-tap filters):
+//     no LDS ring (the span kernel of 5.2 reads count x P cells per output row and carries per-tap branches), no per-row records
+//     over NACC accumulators of which half hold zeros (the accumulator form of 5.3c);
+//   * RING-ALIASED downscales (lanczos at 2x / 4x: windows of 9 / 17 rows on the reference's ring of K = 8 / 16): with K equal
+//     to the reference's ring the aliasing — the first tap reads the slot that already holds the window's last row — happens by
+//     itself, as in the LDS-ring kernel, without its LDS traffic and per-tap slot loads.
+// Edge columns as for the run kernel: stash + resize_edges_kernel.
 // ---------------------------------------------------------------------------------------------
-template <int CH, bool S16, int F, int TX, int P, bool FMA, int RC>
-__global__ __launch_bounds__(256) void resize_up_kernel(RunParams p) {
-    using C = RunCfg<CH, S16, F, 1, TX, P, RC>;
+template <int CH, bool S16, int Q, int PX, int TX, int P, int K, int TYM, bool FMA, int RC>
+__global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
+    using C = RunCfg<CH, S16, Q, PX, TX, P, RC>;
+    constexpr int F = Q;
     static_assert(P % F == 0, "a lane owns whole periods");
     constexpr int NRAW = C::NW;
-    constexpr int NB = 4;  // row buffers == ring length: one unrolled group of four rows
+    constexpr int NB = 4;  // row buffers; K is a multiple of it: one unrolled group of K rows
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
@@ -398,10 +413,12 @@ __global__ __launch_bounds__(256) void resize_up_kernel(RunParams p) {
     for (int q = 0; q < F; ++q)
 #pragma unroll
         for (int j = 0; j < TX; ++j) asm("v_mov_b32 %0, %1" : "=v"(wx[q][j]) : "s"(wbits[q * TX + j]));
-    const int32_t lane_off = (p.x_base + (grp0 + lane) * (P / F)) * C::BPP + sadj;
+    static_assert(K % NB == 0 && TYM <= K + 1, "ring");
+    const int32_t lane_off = (p.x_base + (grp0 + lane) * ((P / F) * PX)) * C::BPP + sadj;
     const bool careful = __any(lane_off < 0);
 
     const_i32_ptr yrange = (const_i32_ptr)(p.yrow_range);
+    const_i32_ptr yneed = (const_i32_ptr)(p.y_info);   // int4 per output row: {., need, ., .}
     const_i32_ptr yleft = (const_i32_ptr)(p.y_left), ycount = (const_i32_ptr)(p.y_count), ywgt = (const_i32_ptr)(p.y_weight);
     const int r0 = yrange[2 * y0], r1 = yrange[2 * (y1 - 1) + 1];
 
@@ -451,9 +468,9 @@ __global__ __launch_bounds__(256) void resize_up_kernel(RunParams p) {
         else load_span<C, false>(src_rs, off, raw[k]);
     }
 
-    float ring[4][P][CH];   // resampled rows, slot = row & 3
+    float ring[K][P][CH];   // resampled rows, slot = (row - r0) mod K
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < K; ++a)
 #pragma unroll
         for (int q = 0; q < P; ++q)
 #pragma unroll
@@ -461,16 +478,16 @@ __global__ __launch_bounds__(256) void resize_up_kernel(RunParams p) {
 
     // the next output row to emit and its window, fetched ahead through the scalar cache
     int y = y0;
-    int yl = yleft[y0], yc = ycount[y0];
-    int wb[4];
+    int yl = yleft[y0], yc = ycount[y0], yn_row = yneed[4 * y0 + 1];
+    int wb[TYM];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) wb[j] = ywgt[(size_t)y0 * p.y_taps + min(j, p.y_taps - 1)];
+    for (int j = 0; j < TYM; ++j) wb[j] = ywgt[(size_t)y0 * p.y_taps + min(j, p.y_taps - 1)];
 
     auto emit = [&](auto base_c) __attribute__((always_inline)) {
         constexpr int B = decltype(base_c)::value;   // ring slot of the window's first row
         float o[P][CH];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < TYM; ++j) {
             if (j < yc) {   // wave-uniform
                 float w;
                 asm volatile("v_mov_b32 %0, %1" : "=v"(w) : "s"(wb[j]));
@@ -478,7 +495,7 @@ __global__ __launch_bounds__(256) void resize_up_kernel(RunParams p) {
                 for (int q = 0; q < P; ++q)
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
-                        const float v = ring[(B + j) & 3][q][c];
+                        const float v = ring[(B + j) % K][q][c];
                         if (j == 0) o[q][c] = w * v;
                         else if constexpr (FMA) o[q][c] = __builtin_fmaf(w, v, o[q][c]);
                         else o[q][c] = o[q][c] + w * v;
@@ -488,8 +505,13 @@ __global__ __launch_bounds__(256) void resize_up_kernel(RunParams p) {
         store_lane_outputs<C, CH, S16, P, FMA>(o, dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
     };
 
+    // wave-uniform dispatch on the slot of the window's first row: K copies of the sum, each with compile-time ring indices
+    auto emit_at = [&](int b0, auto self_c) __attribute__((always_inline)) {
+        (void)self_c;
+        switch_slot<K>(b0, [&](auto bc) __attribute__((always_inline)) { emit(bc); });
+    };
     auto process_row = [&](uint32_t (&cur)[NRAW], int row, auto slot_c) __attribute__((always_inline)) {
-        constexpr int SL = decltype(slot_c)::value;   // == (row - r0 + (r0 & 3)) & 3, i.e. row & 3 with the unroll phase folded in
+        constexpr int SL = decltype(slot_c)::value;   // == (row - r0) mod K
         if (st_wave && row <= r1) stash_row(cur, row);
         // ---- horizontal pass (src/resize.cc:110-117) ----
         uint32_t win[C::BROT ? C::NWIN : 1];
@@ -502,7 +524,7 @@ __global__ __launch_bounds__(256) void resize_up_kernel(RunParams p) {
             else unpack_span_px<C, CH, S16, FMA>(cur, q, u);
 #pragma unroll
             for (int o = 0; o < P; ++o) {
-                const int j = q - run_off(F, 1, o, RC);
+                const int j = q - run_off(Q, PX, o, RC);
                 if (j >= 0 && j < TX) {
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
@@ -517,43 +539,35 @@ __global__ __launch_bounds__(256) void resize_up_kernel(RunParams p) {
         for (int q = 0; q < P; ++q)
 #pragma unroll
             for (int c = 0; c < CH; ++c) ring[SL][q][c] = h[q][c];
-        // ---- every output row whose window ends here (src/resize.cc:121-132) ----
-        while (y < y1 && yl + yc - 1 <= row) {   // wave-uniform
-            switch ((yl - r0) & 3) {               // ring slot of the window's first row: the ring is indexed by row - r0
-            case 0: emit(std::integral_constant<int, 0>{}); break;
-            case 1: emit(std::integral_constant<int, 1>{}); break;
-            case 2: emit(std::integral_constant<int, 2>{}); break;
-            default: emit(std::integral_constant<int, 3>{}); break;
-            }
+        // ---- every output row the reference produces once this row is resampled (src/resize.cc:104,121-132) ----
+        while (y < y1 && yn_row <= row) {   // wave-uniform
+            const int b0 = (yl - r0) & (K - 1);   // ring slot of the window's first row
+            emit_at(b0, std::integral_constant<int, 0>{});
             ++y;
             const int yn = min(y, p.dst_h - 1);
-            yl = yleft[yn]; yc = ycount[yn];
+            yl = yleft[yn]; yc = ycount[yn]; yn_row = yneed[4 * yn + 1];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) wb[j] = ywgt[(size_t)yn * p.y_taps + min(j, p.y_taps - 1)];
+            for (int j = 0; j < TYM; ++j) wb[j] = ywgt[(size_t)yn * p.y_taps + min(j, p.y_taps - 1)];
         }
     };
-    // The unrolled group starts at r0, so position k of a group is ring slot (row - r0) & 3
+    // The unrolled group starts at r0, so position k of a group is ring slot (row - r0) mod K
     auto step = [&](int r, auto k_c) __attribute__((always_inline)) {
-        constexpr int K = decltype(k_c)::value;
-        load_span<C, false>(src_rs, max(1, min(r + K + NB - 1, r1)) * p.src_stride + lane_off, raw[(K + NB - 1) % NB]);
-        if (r + K <= r1) process_row(raw[K], r + K, k_c);
+        constexpr int KK = decltype(k_c)::value;
+        load_span<C, false>(src_rs, max(1, min(r + KK + NB - 1, r1)) * p.src_stride + lane_off, raw[(KK + NB - 1) % NB]);
+        if (r + KK <= r1) process_row(raw[KK % NB], r + KK, k_c);
     };
-    for (int r = r0; r <= r1; r += NB) {
-        step(r, std::integral_constant<int, 0>{});
-        step(r, std::integral_constant<int, 1>{});
-        step(r, std::integral_constant<int, 2>{});
-        step(r, std::integral_constant<int, 3>{});
-    }
+    for (int r = r0; r <= r1; r += K) unroll_steps<K>(r, step);
 }
 
-template <int CH, bool S16, int F, int TX, int P, int RC>
-hipError_t launch_up_t(const RunParams &p, hipStream_t s, const char **name) {
+template <int CH, bool S16, int Q, int PX, int TX, int P, int RC, int K, int TYM>
+hipError_t launch_ring_t(const RunParams &p, hipStream_t s, const char **name) {
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 4;
-    const size_t lds = p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, F, 1, TX, P, RC>::NW + 3) / 4 * 4) : 0;
+    const size_t lds = p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, Q, PX, TX, P, RC>::NW + 3) / 4 * 4) : 0;
     dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
-    if (p.fma) resize_up_kernel<CH, S16, F, TX, P, true, RC><<<grid, 64 * bw, lds, s>>>(p);
-    else resize_up_kernel<CH, S16, F, TX, P, false, RC><<<grid, 64 * bw, lds, s>>>(p);
-    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_up<ch%d,%s,F%d,TX%d,P%d,%s,bw%d%s>", CH, S16 ? "u16" : "u8", F, TX, P, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "");
+    if (p.fma) resize_ring_kernel<CH, S16, Q, PX, TX, P, K, TYM, true, RC><<<grid, 64 * bw, lds, s>>>(p);
+    else resize_ring_kernel<CH, S16, Q, PX, TX, P, K, TYM, false, RC><<<grid, 64 * bw, lds, s>>>(p);
+    if (Q > PX) snprintf(g_kernel_name, sizeof g_kernel_name, "resize_up<ch%d,%s,F%d,TX%d,P%d,%s,bw%d%s>", CH, S16 ? "u16" : "u8", Q, TX, P, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "");
+    else snprintf(g_kernel_name, sizeof g_kernel_name, "resize_ring<ch%d,%s,Q%d,PX%d,TX%d,P%d,K%d,%s,bw%d%s>", CH, S16 ? "u16" : "u8", Q, PX, TX, P, K, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "");
     if (name) *name = g_kernel_name;
     return hipGetLastError();
 }
@@ -601,16 +615,18 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #define PICHA_RUN_LIST_6(X) /* r16g16b16 */
 #define PICHA_RUN_LIST_7(X) /* r16g16b16a16 */
 
-// Upscale instantiations: U(F, TX, P, RC) — integer factor, taps, outputs per lane, window offsets inside a period rounded down / up
-// (2x with picha's defaults: 3 taps with the offsets rounded up; 4-tap filters: rounded down)
-#define PICHA_UP_LIST_0(U) /* rgb */ U(2, 3, 4, 1) U(2, 4, 4, 0) U(4, 4, 8, 0)
-#define PICHA_UP_LIST_1(U) /* rgba */ U(2, 3, 2, 1) U(2, 3, 4, 1) U(2, 4, 2, 0) U(2, 4, 4, 0) U(4, 4, 8, 0)
-#define PICHA_UP_LIST_2(U) /* grey */ U(2, 3, 4, 1) U(2, 3, 8, 1) U(2, 4, 4, 0) U(2, 4, 8, 0) U(4, 4, 8, 0)
-#define PICHA_UP_LIST_3(U) /* greya */ U(2, 3, 4, 1) U(2, 3, 8, 1) U(2, 4, 4, 0) U(2, 4, 8, 0) U(4, 4, 8, 0)
-#define PICHA_UP_LIST_4(U) /* r16 */ U(2, 3, 4, 1) U(2, 3, 8, 1) U(2, 4, 4, 0) U(4, 4, 8, 0)
-#define PICHA_UP_LIST_5(U) /* r16g16 */ U(2, 3, 2, 1) U(2, 3, 4, 1) U(2, 4, 4, 0)
-#define PICHA_UP_LIST_6(U) /* r16g16b16 */ U(2, 3, 2, 1) U(2, 3, 4, 1) U(2, 4, 2, 0)
-#define PICHA_UP_LIST_7(U) /* r16g16b16a16 */   /* four outputs per lane measured 13 % slower than the accumulator form (0.49 against 0.56) */
+// Ring-kernel instantiations: U(Q, PX, TX, P, RC, K, TYM) — period in outputs / source pixels, x taps, outputs per lane, window
+// offsets inside a period rounded down / up, ring rows, most vertical taps.  Upscales (Q = 2, 4; PX = 1; K = 4): 2x with picha's
+// defaults has 3 taps with the offsets rounded up, the 4-tap filters round down.  Ring-aliased downscales: lanczos 2x (9 x 9 taps
+// on a ring of 8).
+#define PICHA_UP_LIST_0(U) /* rgb */ U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4) U(1, 2, 9, 2, 0, 8, 9)
+#define PICHA_UP_LIST_1(U) /* rgba */ U(1, 2, 9, 2, 0, 8, 9) U(2, 1, 3, 2, 1, 4, 4) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 2, 0, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4)
+#define PICHA_UP_LIST_2(U) /* grey */ U(1, 2, 9, 4, 0, 8, 9) U(1, 4, 17, 4, 0, 16, 17) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 3, 8, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(2, 1, 4, 8, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4)
+#define PICHA_UP_LIST_3(U) /* greya */ U(1, 2, 9, 4, 0, 8, 9) U(1, 4, 17, 2, 0, 16, 17) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 3, 8, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(2, 1, 4, 8, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4)
+#define PICHA_UP_LIST_4(U) /* r16 */ U(1, 2, 9, 4, 0, 8, 9) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 3, 8, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4)
+#define PICHA_UP_LIST_5(U) /* r16g16 */ U(1, 2, 9, 2, 0, 8, 9) U(2, 1, 3, 2, 1, 4, 4) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4)
+#define PICHA_UP_LIST_6(U) /* r16g16b16 */ U(1, 2, 9, 2, 0, 8, 9) U(2, 1, 3, 2, 1, 4, 4) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 2, 0, 4, 4)
+#define PICHA_UP_LIST_7(U) /* r16g16b16a16 */ U(1, 2, 9, 2, 0, 8, 9)   /* upscales: four outputs per lane measured 13 % slower than the accumulator form (0.49 against 0.56) */
 
 }  // namespace
 
@@ -643,8 +659,8 @@ hipError_t PICHA_CAT(launch_run_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipS
     return hipErrorInvalidValue;
 }
 
-bool PICHA_CAT(up_supported_pixel, PICHA_RUN_PIXEL)(int f, int tx, int per_lane, int rc) {
-#define U(F, TX, P, RC) if (f == F && tx == TX && per_lane == P && rc == RC) return true;
+bool PICHA_CAT(up_supported_pixel, PICHA_RUN_PIXEL)(int q, int px, int tx, int per_lane, int rc, int ring, int ty) {
+#define U(Q, PX, TX, P, RC, K, TYM) if (q == Q && px == PX && tx == TX && per_lane == P && rc == RC && ring == K && ty <= TYM) return true;
     PICHA_UP_LIST(U)
 #undef U
     return false;
@@ -653,7 +669,7 @@ bool PICHA_CAT(up_supported_pixel, PICHA_RUN_PIXEL)(int f, int tx, int per_lane,
 hipError_t PICHA_CAT(launch_up_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipStream_t s, const char **name) {
     [[maybe_unused]] constexpr int CH = pixel_channels(PICHA_RUN_PIXEL);
     [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
-#define U(F, TX, P, RC) if (p.period == F && p.x_taps == TX && p.x_per_lane == P && p.off_ceil == RC) return launch_up_t<CH, S16, F, TX, P, RC>(p, s, name);
+#define U(Q, PX, TX, P, RC, K, TYM) if (p.period == Q && p.period_px == PX && p.x_taps == TX && p.x_per_lane == P && p.off_ceil == RC && p.ring_rows == K) return launch_ring_t<CH, S16, Q, PX, TX, P, RC, K, TYM>(p, s, name);
     PICHA_UP_LIST(U)
 #undef U
     return hipErrorInvalidValue;
@@ -669,7 +685,7 @@ hipError_t PICHA_CAT(launch_edges_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hi
 #define X(Q, PX, TX, P, RC) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
     PICHA_RUN_LIST(X)
 #undef X
-#define U(F, TX, P, RC) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
+#define U(Q, PX, TX, P, RC, K, TYM) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
     PICHA_UP_LIST(U)
 #undef U
     return hipErrorInvalidValue;

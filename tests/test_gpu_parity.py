@@ -841,6 +841,7 @@ def test_ring_aliased_tables_on_the_accumulator_kernel_match_oracle(pixel):
         exp = oracle_resize(img, dw, dh, filt, 1.0)
         opts = {"width": dw, "height": dh, "filter": filt}
         try:
+            set_opt("run", 2)   # (the ring-in-registers kernel serves some of these by default: its own test is below)
             set_opt("acc", 2)
             ring = picha_amd.resizeSync(img, opts)
             ring_name = N.lib().picha_hip_last_kernel().decode()
@@ -860,9 +861,44 @@ def test_ring_aliased_tables_on_the_accumulator_kernel_match_oracle(pixel):
             got = picha_amd.resizeSync(img, opts)
             assert max_code_diff(got, exp) <= 1, (pixel, sw, filt, "fma", N.lib().picha_hip_last_kernel())
         finally:
-            for k in ("acc", "row_chunks", "acc_p2", "numerics"):
+            for k in ("acc", "row_chunks", "acc_p2", "numerics", "run"):
                 set_opt(k, 0)
     assert served >= 18, served
+
+
+@pytest.mark.parametrize("pixel", PIXELS)
+def test_ring_in_registers_kernel_on_aliased_downscales_matches_oracle(pixel):
+    """r03: resize_ring_kernel (kernels_run.hip) keeps the reference's ring of resampled rows in registers (slot = row mod ring):
+    lanczos at 2x (9 taps on a ring of 8) for every format, at 4x (17 on 16) for grey / greya; with the reference's ring length the
+    aliasing of the first tap happens by itself.  Against the oracle, run lengths, chunkings, both numerics, a device batch."""
+    from picha_amd.device import DeviceBatch, resize_batch
+    import torch
+    rng = np.random.default_rng(4300 + PIXELS.index(pixel))
+    served = 0
+    for (sw, sh, dw, dh) in [(640, 96, 320, 48), (1030, 77, 515, 38), (512, 128, 128, 32), (768, 200, 192, 50)]:
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8])), edge_values=bool(rng.integers(0, 3) == 0))
+        exp = oracle_resize(img, dw, dh, "lanczos", 1.0)
+        opts = {"width": dw, "height": dh, "filter": "lanczos"}
+        try:
+            for run, per_lane, chunks, numerics in ((0, 0, 0, 0), (1, 0, 1, 0), (1, 2, 3, 0), (1, 4, 2, 0), (1, 0, 0, 1)):
+                set_opt("run", run)
+                set_opt("per_lane", per_lane)
+                set_opt("row_chunks", chunks)
+                set_opt("numerics", numerics)
+                got = picha_amd.resizeSync(img, opts)
+                name = N.lib().picha_hip_last_kernel().decode()
+                served += name.startswith("resize_ring<")
+                assert max_code_diff(got, exp) <= numerics, (pixel, sw, sh, dw, dh, run, per_lane, chunks, numerics, name)
+        finally:
+            for k in ("run", "per_lane", "row_chunks", "numerics"):
+                set_opt(k, 0)
+    assert served >= 4, served
+    src = DeviceBatch(6, 640, 96, pixel).fill_random(9)
+    out = resize_batch(src, 320, 48, filter="lanczos")
+    torch.cuda.synchronize()
+    assert N.lib().picha_hip_last_kernel().decode().startswith("resize_ring<")
+    for i in range(6):
+        assert np.array_equal(out.image_host(i).pixels(), oracle_resize(src.image_host(i), 320, 48, "lanczos", 1.0).pixels()), i
 
 
 def test_ring_aliased_long_windows_take_the_accumulator_kernel_by_default():
@@ -874,8 +910,9 @@ def test_ring_aliased_long_windows_take_the_accumulator_kernel_by_default():
         ("rgb", 1536, 300, 128, 25, "lanczos", "resize_acc_long<ch3,u8,TX"),
         ("grey", 1024, 264, 128, 33, "lanczos", "resize_acc<ch1,u8,TX36,NACC6"),
         ("rgb", 512, 128, 128, 32, "lanczos", "resize_acc<ch3,u8,TX"),
-        ("grey", 512, 128, 128, 32, "lanczos", "resize_span<ch1,u8"),
-        ("rgba", 640, 96, 320, 48, "lanczos", "resize_span<ch4,u8"),
+        ("grey", 512, 128, 128, 32, "lanczos", "resize_ring<ch1,u8,Q1,PX4,TX17,P4,K16"),   # 4x, grey: the ring-in-registers kernel
+        ("rgba", 640, 96, 320, 48, "lanczos", "resize_ring<ch4,u8,Q1,PX2,TX9,P2,K8"),      # 2x: the ring-in-registers kernel
+        ("rgba", 512, 128, 128, 32, "box", "resize_span<ch4,u8"),
         ("rgba", 512, 64, 128, 16, "box", "resize_span<ch4,u8"),
     ]:
         img = rand_image(rng, sw, sh, pixel)
