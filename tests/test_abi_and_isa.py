@@ -123,7 +123,7 @@ def test_reference_arithmetic_kernels_have_no_fused_multiply_add(device_disassem
             re.search(r"resize_sym_kernelI.*ELb([01])ELb[01]EEEvNS_", name) or \
             re.search(r"resize_rows_kernelI.*ELb([01])EEEvNS_", name) or \
             re.search(r"resize_run_kernelI.*ELb([01])ELi[01]EEEvNS_", name) or \
-            re.search(r"resize_up_kernelI.*ELb([01])ELi[01]EEEvNS_", name)  # <..., FMA, RC>; resize_edges_kernel is reference arithmetic only
+            re.search(r"resize_ring_kernelI.*ELb([01])ELi[01]EEEvNS_", name)  # <..., FMA, RC>; resize_edges_kernel is reference arithmetic only
         if m and m.group(1) == "1":
             fma_flavour += 1
             assert body["fused"], "fma flavour without fma? " + name
@@ -135,7 +135,7 @@ def test_reference_arithmetic_kernels_have_no_fused_multiply_add(device_disassem
 
 def test_kernels_are_gfx950_wave64_without_scratch_spills(device_disassembly):
     funcs = device_disassembly
-    hot = [k for k in funcs if "resize_stream_kernel" in k or "color_convert_kernel" in k or "resize_acc_kernel" in k or "resize_sym_kernel" in k or "resize_rows_kernel" in k or "resize_run_kernel" in k or "resize_up_kernel" in k or "resize_edges_kernel" in k]
+    hot = [k for k in funcs if "resize_stream_kernel" in k or "color_convert_kernel" in k or "resize_acc_kernel" in k or "resize_sym_kernel" in k or "resize_rows_kernel" in k or "resize_run_kernel" in k or "resize_ring_kernel" in k or "resize_edges_kernel" in k]
     assert hot
     for k in hot:
         assert funcs[k]["scratch"] == 0, "scratch traffic in " + k
