@@ -971,7 +971,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     const int32_t *up_range = nullptr;
     int nacc = 0, per_lane = 0, ktaps = 0, ceil_off = 0;
     // Three vertical schemes: the march with per-source-row records (downscales without ring aliasing); the ring-in-registers kernel
-    // for upscales (ring of four rows) and for ring-aliased downscales whose reference ring is 8 or 16 rows (lanczos at 2x / 4x).
+    // for upscales (ring of four rows) and for ring-aliased downscales whose reference ring is 8 or 16 rows (lanczos at 2x / 4x; at odd factors its windows do not alias).
     // The register ring reproduces the reference's ring whenever it has the reference's length, or the table has no aliasing and
     // no output row needs more rows than the ring holds (taps.cpp: eff[] = the last row <= need[] in the tap's residue class).
     int ring_rows = 0;

@@ -541,7 +541,7 @@ __global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
             for (int c = 0; c < CH; ++c) ring[SL][q][c] = h[q][c];
         // ---- every output row the reference produces once this row is resampled (src/resize.cc:104,121-132) ----
         while (y < y1 && yn_row <= row) {   // wave-uniform
-            const int b0 = (yl - r0) & (K - 1);   // ring slot of the window's first row
+            const int b0 = (yl - r0) % K;   // ring slot of the window's first row (yl >= r0)
             emit_at(b0, std::integral_constant<int, 0>{});
             ++y;
             const int yn = min(y, p.dst_h - 1);
