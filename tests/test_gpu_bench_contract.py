@@ -40,7 +40,7 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
 
 
 def test_bench_other_workloads_run():
-    for w in ("cfg3a_4k_rgb_to_grey", "cfg3_4k_rgb_to_grey_to_512_lanczos_chained", "edge_deep_png_4k_rgba16_to_1080p_rgba", "up_960x540_r16_to_1080p"):
+    for w in ("cfg3a_4k_rgb_to_grey", "cfg3_4k_rgb_to_grey_to_512_lanczos_chained", "edge_deep_png_4k_rgba16_to_1080p_rgba", "up_960x540_r16_to_1080p", "lanczos_4k_rgba_to_1080p"):
         d = _run("--workload", w, "--images", "4", "--steps", "2", "--warmup", "1", "--prewarm-ms", "0", "--no-cpu-baseline")
         assert d["value"] > 0 and d["roofline"]["frac"] > 0 and d["config"]["parity_max_code_diff_vs_oracle_image0"] == 0
         if w.startswith("edge_deep_png"):
