@@ -124,6 +124,7 @@ EPILOGUE_CASES = [
     ("r16g16b16a16", "rgb", (480, 96), (160, 32), "cubic", 0.70),
     ("rgba", "r16g16b16a16", (300, 200), (150, 100), "triangle", 1.0),   # 3 taps -> bucket 5, 8 -> 16 bit
     ("grey", "greya", (256, 256), (128, 128), "cubic", 0.70),
+    ("r16g16b16a16", "rgba", (512, 128), (256, 64), "lanczos", 1.0),     # ring-aliased vertical table (9 taps on a ring of 8): the row list under the epilogue
 ]
 
 
