@@ -1012,7 +1012,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         const int c = (tx_of[1] > 0 && tx_of[1] < tx_of[0]) ? 1 - k : k;   // the shorter window first
         if (tx_of[c] <= 0 || (period == 1 && c == 1) || (opt_run_round != 0 && opt_run_round != c + 1)) continue;
         for (int tx = tx_of[c]; tx <= tx_of[c] + 3 && !per_lane; ++tx)
-            for (int pl0 : (up ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
+            for (int pl0 : (up || (period == 2 && period_px == 3) ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
                 const int pl = opt_per_lane > 0 ? (int)opt_per_lane : pl0;   // "per_lane" names the run length outright
                 if (pl % period || !(ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c))) continue;
                 per_lane = pl; ktaps = tx; ceil_off = c;
@@ -1023,7 +1023,9 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // where it is the default (same survey): windows of 26 taps and more (cfg3b: -3 % reference arithmetic, -10 % fma against the
     // row-staged kernel; greya -35 %); shorter windows only for batches that still fill the chip with a quarter of the
     // accumulator kernel's waves (256 x 4K -> 512x288 grey: -11 %; 128 images: a tie; integer scales 6x / 8x: -9 .. -13 % at 128 images)
-    if (!ring_mode && opt_run == 0 && ktaps < 26 && !(kChannels[pixel] == 1 && n >= (period == 1 ? 96 : 192))) return PICHA_OK;
+    // ... and 1.5x (1080p -> 720p: 4 taps, eight outputs per lane: grey -31 %, greya -9 % on 256 images)
+    const bool x15 = period == 2 && period_px == 3 && kChannels[pixel] <= 2 && n >= 96;
+    if (!ring_mode && opt_run == 0 && ktaps < 26 && !x15 && !(kChannels[pixel] == 1 && n >= (period == 1 ? 96 : 192))) return PICHA_OK;
     const DeviceAxis::RunTable *rt = nullptr;
     rc = get_runtable(ctx, ax, period, period_px, ceil_off, ktaps, wmode, is16, &rt);
     if (rc) return rc;

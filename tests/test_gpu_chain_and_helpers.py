@@ -221,9 +221,11 @@ RUN_CASES = [   # pixel, source, destination, filter, filter scale, (period in o
     ("greya", (1950, 150), (260, 20), "cubic", 0.70, (2, 15, 21)),     # five row pieces of 64 lanes, the last one ragged
     ("grey", (1920, 180), (320, 30), "cubic", 0.70, (1, 6, 17)),       # integer scale, period 1: 6x, 17 taps
     ("grey", (2048, 240), (256, 41), "cubic", 0.70, (1, 8, 23)),       # 8x, 23 taps: four or eight outputs per lane
+    ("grey", (960, 150), (640, 100), "cubic", 0.70, (2, 3, 4)),        # 1.5x: period 2 / 3 source pixels, 4 taps (offsets rounded up)
+    ("greya", (1230, 90), (820, 60), "cubic", 0.70, (2, 3, 4)),
 ]
 RUN_PER_LANE = {("grey", 2, 21): (0, 2, 4, 8), ("grey", 2, 31): (0, 2, 4), ("greya", 2, 21): (0, 2), ("greya", 2, 31): (0, 2, 4),
-                ("grey", 1, 17): (0, 4), ("grey", 1, 23): (0, 4, 8)}
+                ("grey", 1, 17): (0, 4), ("grey", 1, 23): (0, 4, 8), ("grey", 2, 4): (0, 4, 8), ("greya", 2, 4): (0, 4, 8)}
 
 
 @pytest.mark.parametrize("case", RUN_CASES, ids=lambda c: "%s-%dx%d-%s" % (c[0], c[1][0], c[1][1], c[3]))
@@ -255,7 +257,7 @@ def test_run_kernel_matches_oracle(case):
                 N.check(N.lib().picha_hip_set_option(b"work", work))
                 got = picha.resizeSync(img, opts)
                 name = N.lib().picha_hip_last_kernel().decode()
-                pl = per_lane or (4 if ch == 1 else 2)
+                pl = per_lane or (8 if taps == 4 else 4 if ch == 1 else 2)
                 # 31 taps: 30 with the window offsets rounded up (",ceil"), where that form is instantiated
                 assert re.match(r"resize_run<ch%d,u8,Q%d,PX%d,TX(%d|%d),P%d," % (ch, period, period_px, taps, taps - 1, pl), name), name
                 assert "+ resize_edges<" in name, name

@@ -118,14 +118,14 @@ def test_random_resizes_match_oracle(seed):
 
 @pytest.mark.parametrize("seed", range(max(2, N_SEEDS // 3)))
 def test_random_half_integer_downscales_match_oracle(seed):
-    """r03: 7.5x in x (the run kernel's period 2 / 15 pixels) with random heights, strides, sub-views, filters and launch options;
+    """r03: 7.5x or 1.5x in x (the run kernel's periods 2 / 15 and 2 / 3 pixels) with random heights, strides, sub-views, filters and launch options;
     grey and greya take the run kernel + edge kernel where an instantiation exists (21 / 31 taps), everything else falls through
     to the other kernels — all of it against the oracle."""
     rng = np.random.default_rng(BASE + 7000 + seed)
     ran = 0
     for _ in range(40):
         dw = 2 * int(rng.integers(2, 200))
-        sw = dw * 15 // 2
+        sw = dw * (15 if rng.integers(0, 3) else 3) // 2      # 7.5x, or 1.5x (period 2 / 3 source pixels)
         dh = int(rng.integers(1, 60))
         sh = dh * int(rng.integers(1, 9)) + int(rng.integers(1, 7))
         pixel = str(rng.choice(["grey", "grey", "greya", "greya", "rgb", "r16"]))
