@@ -154,7 +154,7 @@ int picha_hip_device_arch(char *buf, size_t len);
  *                with wave-uniform weights; the edge columns come from a second small kernel) and its upscale form
  *                (resize_up: exactly 2x / 4x in x, vertical windows of at most four rows) and ring-aliased form (resize_ring:
  *                lanczos at 2x / 4x): 0 = auto (downscales: grey / greya
- *                with >= 26 taps, shorter grey windows for batches of >= 192 images; 2x upscales: every format with an
+ *                with >= 26 taps, their shorter instantiated windows (1.5x .. 8x) for batches of >= 96 images; 2x upscales: every format with an
  *                instantiation), 1 = wherever an instantiation exists, 2 = never.  "per_lane" (2, 4, 8), "row_chunks", "block_waves" and "work" (1, 2; default
  *                plain grid) apply to it too
  *   "run_round"  its window offsets inside a period: 0 = auto (the rounding with the shorter window), 1 = down, 2 = up

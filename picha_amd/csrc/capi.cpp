@@ -1023,9 +1023,11 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // where it is the default (same survey): windows of 26 taps and more (cfg3b: -3 % reference arithmetic, -10 % fma against the
     // row-staged kernel; greya -35 %); shorter windows only for batches that still fill the chip with a quarter of the
     // accumulator kernel's waves (256 x 4K -> 512x288 grey: -11 %; 128 images: a tie; integer scales 6x / 8x: -9 .. -13 % at 128 images)
-    // ... and 1.5x (1080p -> 720p: 4 taps, eight outputs per lane: grey -31 %, greya -9 % on 256 images)
-    const bool x15 = period == 2 && period_px == 3 && kChannels[pixel] <= 2 && n >= 96;
-    if (!ring_mode && opt_run == 0 && ktaps < 26 && !x15 && !(kChannels[pixel] == 1 && n >= (period == 1 ? 96 : 192))) return PICHA_OK;
+    // ... and the other instantiated shapes of one- and two-channel pixels (1.5x: grey -31 %, greya -9 %; 2.5x / 3x / 4x / 5x: -11 .. -26 %,
+    // measured on 128-256 images); the 21-tap 7.5x shape was a tie for greya and needs >= 192 images for grey
+    const int ch = kChannels[pixel];
+    const bool short_ok = period_px == 15 ? (ch == 1 && n >= 192) : (ch <= 2 && n >= 96);
+    if (!ring_mode && opt_run == 0 && ktaps < 26 && !short_ok) return PICHA_OK;
     const DeviceAxis::RunTable *rt = nullptr;
     rc = get_runtable(ctx, ax, period, period_px, ceil_off, ktaps, wmode, is16, &rt);
     if (rc) return rc;

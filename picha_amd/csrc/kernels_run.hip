@@ -607,11 +607,12 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // accumulator kernel (fma -14 % / -4 %); greya, rgb, rgba -2 .. +7 %: not instantiated.  (lanczos at those scales is ring-aliased in y:
 // the accumulator kernel's row list serves it, capi.cpp get_yrows.)  1.5x (period 2 / 3 source pixels, 4 taps with the offsets rounded up;
 // 256 x 1080p -> 720p, profiles/r03_ab_run_kernel.txt): grey with eight outputs per lane -31 % (fma -40 %), greya -9 %; rgb +5 %, rgba -1 %:
-// not instantiated.
+// not instantiated.  More periodic scales with picha's defaults (128 x 4K sources, scripts/r03_call_scales.sh, same file): grey 2.5x -26 %, 3x -11 %,
+// 5x -11 % (4x: a tie with the streaming kernel); greya 2.5x -11 %, 4x -14 %, 5x -11 % (3x: the symmetric-table kernel stays ahead).
 #define PICHA_RUN_LIST_0(X) /* rgb */
 #define PICHA_RUN_LIST_1(X) /* rgba */
-#define PICHA_RUN_LIST_2(X) /* grey */ X(2, 3, 4, 8, 1) X(2, 3, 4, 4, 1) X(1, 6, 17, 4, 0) X(1, 8, 23, 4, 0) X(1, 8, 23, 8, 0) X(2, 15, 21, 2, 0) X(2, 15, 21, 4, 0) X(2, 15, 21, 8, 0) X(2, 15, 31, 2, 0) X(2, 15, 31, 4, 0) X(2, 15, 30, 4, 1)
-#define PICHA_RUN_LIST_3(X) /* greya */ X(2, 3, 4, 8, 1) X(2, 3, 4, 4, 1) X(2, 15, 21, 2, 0) X(2, 15, 31, 2, 0) X(2, 15, 31, 4, 0) X(2, 15, 30, 2, 1)
+#define PICHA_RUN_LIST_2(X) /* grey */ X(1, 3, 8, 8, 0) X(1, 5, 14, 4, 0) X(2, 5, 7, 8, 1) X(2, 3, 4, 8, 1) X(2, 3, 4, 4, 1) X(1, 6, 17, 4, 0) X(1, 8, 23, 4, 0) X(1, 8, 23, 8, 0) X(2, 15, 21, 2, 0) X(2, 15, 21, 4, 0) X(2, 15, 21, 8, 0) X(2, 15, 31, 2, 0) X(2, 15, 31, 4, 0) X(2, 15, 30, 4, 1)
+#define PICHA_RUN_LIST_3(X) /* greya */ X(1, 4, 11, 4, 0) X(1, 5, 14, 4, 0) X(2, 5, 7, 4, 1) X(2, 3, 4, 8, 1) X(2, 3, 4, 4, 1) X(2, 15, 21, 2, 0) X(2, 15, 31, 2, 0) X(2, 15, 31, 4, 0) X(2, 15, 30, 2, 1)
 #define PICHA_RUN_LIST_4(X) /* r16 */
 #define PICHA_RUN_LIST_5(X) /* r16g16 */
 #define PICHA_RUN_LIST_6(X) /* r16g16b16 */

@@ -223,9 +223,18 @@ RUN_CASES = [   # pixel, source, destination, filter, filter scale, (period in o
     ("grey", (2048, 240), (256, 41), "cubic", 0.70, (1, 8, 23)),       # 8x, 23 taps: four or eight outputs per lane
     ("grey", (960, 150), (640, 100), "cubic", 0.70, (2, 3, 4)),        # 1.5x: period 2 / 3 source pixels, 4 taps (offsets rounded up)
     ("greya", (1230, 90), (820, 60), "cubic", 0.70, (2, 3, 4)),
+    ("grey", (1280, 90), (512, 36), "cubic", 0.70, (2, 5, 7)),         # 2.5x
+    ("greya", (640, 75), (256, 30), "cubic", 0.70, (2, 5, 7)),
+    ("grey", (1536, 90), (512, 30), "cubic", 0.70, (1, 3, 8)),         # 3x
+    ("greya", (1024, 64), (256, 16), "cubic", 0.70, (1, 4, 11)),       # 4x
+    ("grey", (1280, 100), (256, 20), "cubic", 0.70, (1, 5, 14)),       # 5x
+    ("greya", (1280, 100), (256, 20), "cubic", 0.70, (1, 5, 14)),
 ]
-RUN_PER_LANE = {("grey", 2, 21): (0, 2, 4, 8), ("grey", 2, 31): (0, 2, 4), ("greya", 2, 21): (0, 2), ("greya", 2, 31): (0, 2, 4),
-                ("grey", 1, 17): (0, 4), ("grey", 1, 23): (0, 4, 8), ("grey", 2, 4): (0, 4, 8), ("greya", 2, 4): (0, 4, 8)}
+# (default outputs per lane, the other instantiated run lengths)
+RUN_PER_LANE = {("grey", 2, 21): (4, (2, 8)), ("grey", 2, 31): (4, (2,)), ("greya", 2, 21): (2, ()), ("greya", 2, 31): (2, (4,)),
+                ("grey", 1, 17): (4, ()), ("grey", 1, 23): (4, (8,)), ("grey", 2, 4): (8, (4,)), ("greya", 2, 4): (8, (4,)),
+                ("grey", 2, 7): (8, ()), ("greya", 2, 7): (4, ()), ("grey", 1, 8): (8, ()), ("greya", 1, 11): (4, ()),
+                ("grey", 1, 14): (4, ()), ("greya", 1, 14): (4, ())}
 
 
 @pytest.mark.parametrize("case", RUN_CASES, ids=lambda c: "%s-%dx%d-%s" % (c[0], c[1][0], c[1][1], c[3]))
@@ -250,14 +259,15 @@ def test_run_kernel_matches_oracle(case):
             got = picha.resizeSync(img, opts)
             assert max_code_diff(got, want) == 0, (case, rnd, N.lib().picha_hip_last_kernel())
         N.check(N.lib().picha_hip_set_option(b"run_round", 0))
-        for per_lane in RUN_PER_LANE[(pixel, period, taps)]:
+        default_pl, other_pl = RUN_PER_LANE[(pixel, period, taps)]
+        for per_lane in (0,) + (default_pl,) + tuple(other_pl):
             for chunks, work in ((0, 0), (1, 3), (3, 1), (2, 2)):
                 N.check(N.lib().picha_hip_set_option(b"per_lane", per_lane))
                 N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
                 N.check(N.lib().picha_hip_set_option(b"work", work))
                 got = picha.resizeSync(img, opts)
                 name = N.lib().picha_hip_last_kernel().decode()
-                pl = per_lane or (8 if taps == 4 else 4 if ch == 1 else 2)
+                pl = per_lane or default_pl
                 # 31 taps: 30 with the window offsets rounded up (",ceil"), where that form is instantiated
                 assert re.match(r"resize_run<ch%d,u8,Q%d,PX%d,TX(%d|%d),P%d," % (ch, period, period_px, taps, taps - 1, pl), name), name
                 assert "+ resize_edges<" in name, name
