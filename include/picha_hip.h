@@ -158,6 +158,7 @@ int picha_hip_device_arch(char *buf, size_t len);
  *                instantiation), 1 = wherever an instantiation exists, 2 = never.  "per_lane" (2, 4, 8), "row_chunks", "block_waves" and "work" (1, 2; default
  *                plain grid) apply to it too
  *   "run_round"  its window offsets inside a period: 0 = auto (the rounding with the shorter window), 1 = down, 2 = up
+ *                ("run" = 3 is a measurement aid: the run kernel WITHOUT its edge columns — those come out wrong)
  *   "fuse"       picha_hip_convert_resize*: 0 = one fused kernel where it exists and was measured faster (default: every
  *                convert -> downscale pair of the row-staged kernel; resize -> convert for 16-bit and rgba sources), 1 = one
  *                kernel wherever an instantiation exists, 2 = always two kernels
