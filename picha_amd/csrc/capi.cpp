@@ -86,6 +86,7 @@ long g_opt_cc_mode = 0;     // colour convert: 0 auto (wide kernel when rows are
 long g_opt_sym = 0;         // symmetric-table streaming kernel (kernels_sym.hip): 0 auto (when available), 2 never
 long g_opt_block_waves = 0; // its waves per workgroup (0 auto)
 long g_opt_acc_p2 = 0;      // accumulator kernel with two outputs per lane: 0 auto (measured table), 1 whenever possible, 2 never
+long g_opt_long_block = 0;  // long-window accumulator kernel: threads per workgroup (0 auto, 64 / 128 / 192 / 256)
 long g_opt_sym_sync = 0;    // 1: a barrier per step keeps the waves of a workgroup in lockstep
 long g_opt_work = 0;        // sym / accumulator kernels, work items: 0 auto, 1 explicit item list (one workgroup per item, short chunks last),
                             // 2 persistent launch (resident workgroups pull items from per-XCD atomic queues), 3 plain 3-D grid
@@ -1377,14 +1378,14 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     if (rc) return rc;
     DeviceAxis *ax = ax_ref.get(), *ay = ay_ref.get();
 
-    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_bw, opt_sym_sync, opt_acc_p2, opt_xch;
+    long opt_path, opt_chunks, opt_numerics, opt_per_lane, opt_rot, opt_dpp, opt_xcd, opt_acc, opt_sym, opt_bw, opt_sym_sync, opt_acc_p2, opt_xch, opt_long_block;
     long opt_work, opt_work_tail, opt_work_tail_div, opt_up;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         opt_up = g_opt_up;
         opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
         opt_xch = g_opt_xch;
-        opt_sym = g_opt_sym; opt_bw = g_opt_block_waves; opt_sym_sync = g_opt_sym_sync; opt_acc_p2 = g_opt_acc_p2;
+        opt_sym = g_opt_sym; opt_bw = g_opt_block_waves; opt_sym_sync = g_opt_sym_sync; opt_acc_p2 = g_opt_acc_p2; opt_long_block = g_opt_long_block;
         opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
         opt_rot = g_opt_stream_rot;
         opt_dpp = g_opt_dpp;
@@ -1677,7 +1678,8 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     // (window rows) x 64 lanes x 4..16 B of LDS per wave and caps the occupancy (a 7.5x thumbnail: 22 KB per wave,
     // 7 waves per CU); the accumulator kernel keeps nacc x channels registers instead.
     constexpr int kAccMinRing = 1;  // measured faster than the span kernel for every ring size it was tried on (profiles/r01_survey_acc_vs_span.txt)
-    const bool acc_long = !yr && ataps == 0 && ax->host.taps > 36 && ax->host.taps <= 128;
+    // no bucket (above 36 taps; 34..36 for odd pixel sizes and 36 for 2- and 6-byte pixels, whose aligned fetch needs room)
+    const bool acc_long = !yr && ataps == 0 && ax->host.taps > 32 && ax->host.taps <= 128;
     if (acc_long) {  // long windows: LDS-resident weights, tap count padded to half a load segment
         const int half = acc_long_segment(kBytes[pixel]) / 2;
         ataps = (ax->host.taps + half - 1) / half * half;
@@ -1783,6 +1785,25 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         p.ring_slots = ring;
         p.xcd_remap = opt_xcd == 1 ? 1 : 0;
         if (use_acc) { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.yrow_src = yr->src; p.nacc = nacc; p.x_per_lane = acc_per_lane; p.x_step = acc_x_step; p.xch = acc_xch ? 1 : 0; }
+        if (acc_long) {
+            // workgroup of 1..4 waves: the x weights of a wave take x_taps * 256 B of LDS, which bounds the waves a CU holds, and a
+            // thumbnail is only 3-8 waves wide, so the waves of a partly used workgroup exit at once and leave their LDS idle.
+            // Score = live resident waves per CU, full four-wave workgroups favoured (their waves share rows: measured 10-25 %
+            // ahead of single waves at equal residency for pixels of up to 4 bytes, behind for 8-byte pixels);
+            // profiles/r03_ab_acc_long.txt
+            const int cw = (d0.width + 63) / 64;
+            double best = -1.0;
+            int bw = 1;
+            for (int k = 1; k <= 4; ++k) {
+                const long long lds = (long long)ataps * k * 256;
+                const int blocks = (int)std::min<long long>(163840 / lds, 16 / k);
+                const double live = (double)cw / ((cw + k - 1) / k * k);
+                const double bonus = k == 4 ? (kBytes[pixel] >= 6 ? 1.0 : (kBytes[pixel] >= 3 ? 1.3 : 1.2)) : (k == 3 ? 1.05 : 1.0);
+                const double sc = blocks * k * live * bonus;
+                if (sc > best + 1e-9) { best = sc; bw = k; }
+            }
+            p.long_block = opt_long_block >= 64 && opt_long_block <= 256 && opt_long_block % 64 == 0 ? (int)opt_long_block : 64 * bw;
+        }
         if (epi) { p.epi_on = 1; p.epi_pixel = d0.pixel; p.epi_r = epi->r; p.epi_g = epi->g; p.epi_b = epi->b; if (epi_used) *epi_used = true; }
         // row chunks: enough waves to fill 256 CUs several times over (~32 K), but every chunk re-resamples the `ring`
         // source rows above its first output: keep that halo under ~6 % of the chunk's own source rows unless the
@@ -2201,6 +2222,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "work_tail") == 0) { g_opt_work_tail = value; return PICHA_OK; }
     if (strcmp(key, "work_tail_div") == 0) { g_opt_work_tail_div = value; return PICHA_OK; }
     if (strcmp(key, "acc_p2") == 0) { g_opt_acc_p2 = value; return PICHA_OK; }
+    if (strcmp(key, "long_block") == 0) { g_opt_long_block = value; return PICHA_OK; }
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
     if (strcmp(key, "acc") == 0) { g_opt_acc = value; return PICHA_OK; }
     if (strcmp(key, "async_devices") == 0) { g_opt_async_devices = value; return PICHA_OK; }
@@ -2231,6 +2253,7 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "work_tail") == 0) return g_opt_work_tail;
     if (strcmp(key, "work_tail_div") == 0) return g_opt_work_tail_div;
     if (strcmp(key, "acc_p2") == 0) return g_opt_acc_p2;
+    if (strcmp(key, "long_block") == 0) return g_opt_long_block;
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;
     if (strcmp(key, "acc") == 0) return g_opt_acc;
     if (strcmp(key, "async_devices") == 0) return g_opt_async_devices;

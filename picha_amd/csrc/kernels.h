@@ -99,6 +99,7 @@ struct FusedParams {
     // LIST of source rows — every row in order, plus, ahead of each aliased window, the window's last row once more, whose record
     // carries the aliased first tap's weight — and yrow_src[position] is the source row to resample (nullptr: position == row)
     const int32_t *yrow_src;    // [list length + 8] or nullptr
+    int long_block;             // resize_acc_long_kernel: threads per workgroup (64 / 128 / 192 / 256)
     int nacc;
     int xch;  // accumulator kernel, neighbour-exchange form: a lane loads only its own x_step * x_per_lane pixels (uniform-base x table)
     WorkList work;  // accumulator kernel only: explicit work items / persistent launch
@@ -113,6 +114,9 @@ struct FusedParams {
 // 8-pixel segments cost +35 %, 32-pixel segments of rgba +19 %, of grey -27 %) plus an optional half segment at the end,
 // so its tap count is a multiple of half a segment.
 constexpr int acc_long_segment(int bytes_per_pixel) { return bytes_per_pixel <= 3 ? 32 : (bytes_per_pixel <= 6 ? 16 : 8); }
+// ... with this many segment buffers per wave (r03, profiles/r03_ab_acc_long.txt: four in flight are 0-10 % faster than two for
+// pixels of up to 4 bytes, 0-15 % slower for 8-byte pixels)
+constexpr int acc_long_bufs(int bytes_per_pixel) { return bytes_per_pixel <= 4 ? 4 : 2; }
 bool acc_supported(int pixel, int x_taps_bucket, int nacc);
 bool acc_p2_supported(int pixel, int step, int taps, int nacc);  // two outputs per lane: window of the second `step` pixels after the first
 bool acc_xch_supported(int pixel, int per_lane, int step, int taps, int nacc);  // neighbour-exchange form (dword-sized pixels)

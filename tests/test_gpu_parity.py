@@ -822,6 +822,33 @@ def test_long_window_accumulator_kernel(pixel):
 
 
 @pytest.mark.parametrize("pixel", PIXELS)
+def test_windows_of_33_to_36_taps_have_a_one_pass_kernel_for_every_format(pixel):
+    """r03: the accumulator kernel's tap buckets end at 36 and the aligned fetch of the 1-, 2-, 3- and 6-byte pixels needs room
+    inside the bucket, so their 34..36-tap windows (a 12 Mpixel photo to a 320-wide thumbnail with default options) had no bucket
+    and, being no longer than 36 taps, did not take the long-window kernel either: two-pass, 15-30x slower.  Every workgroup
+    size of the long-window kernel is checked against the oracle on the way."""
+    rng = np.random.default_rng(950 + PIXELS.index(pixel))
+    for (sw, sh, dw, dh, filt, fscale) in [(1260, 96, 100, 24, "cubic", 0.70), (1008, 60, 80, 15, "cubic", 0.70), (2304, 50, 256, 10, "cubic", 1.0),
+                                             (1180, 40, 100, 10, "cubic", 0.70), (700, 40, 50, 10, "catmulrom", 1.0), (1488, 33, 340, 7, "lanczos", 1.0)]:
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8])))
+        opts = {"width": dw, "height": dh}
+        if not (filt == "cubic" and fscale == 0.70):
+            opts["filter"] = filt
+        exp = oracle_resize(img, dw, dh, filt, fscale)
+        for block in (0, 64, 128, 192, 256):
+            set_opt("long_block", block)
+            try:
+                got = picha_amd.resizeSync(img, opts)
+            finally:
+                set_opt("long_block", 0)
+            name = N.lib().picha_hip_last_kernel().decode()
+            assert name != "twopass", (pixel, sw, dw, name)
+            assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, filt, block, name)
+            if block and "acc_long" in name:
+                assert name.endswith(",bw%d>" % (block // 64)), name
+
+
+@pytest.mark.parametrize("pixel", PIXELS)
 def test_ring_aliased_tables_on_the_accumulator_kernel_match_oracle(pixel):
     """r03: lanczos and box at even integer scales make the reference's ring one row short (src/resize.cc:52-64): the first tap of
     every output row reads the window's LAST row.  The accumulator kernel follows a row LIST in which that row appears once more
