@@ -1701,7 +1701,8 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         // greya from 24, grey from 26 (the ring of one float per lane is cheap: a tie at 6x); box and lanczos 2x stay on the ring
         if (yr && yr->src && opt_acc != 1 && opt_path != 4) {
             const int ty = ay->host.taps, ch = kChannels[pixel];
-            if (!(ty > 32 || (ch >= 3 && ty >= 16) || (ch == 2 && ty >= 24) || (ch == 1 && ty >= 26))) { yr = nullptr; nacc = 0; }
+            // (long x windows have no ring kernel to go back to: the alternative would be the two-pass kernels)
+            if (!(acc_long || ty > 32 || (ch >= 3 && ty >= 16) || (ch == 2 && ty >= 24) || (ch == 1 && ty >= 26))) { yr = nullptr; nacc = 0; }
         }
         // two outputs per lane (r02): the union of both windows is loaded and converted once; option "acc_p2": 0 auto (where
         // acc_p2_preferred says it was measured faster), 1 whenever a shape exists, 2 never

@@ -849,6 +849,20 @@ def test_windows_of_33_to_36_taps_have_a_one_pass_kernel_for_every_format(pixel)
 
 
 @pytest.mark.parametrize("pixel", PIXELS)
+def test_long_x_windows_with_a_ring_aliased_y_table_stay_one_pass(pixel):
+    """r03 (scripts/scan_fallbacks.py): lanczos / box at an even integer y scale (aliased ring, short enough for the LDS-ring
+    kernel by the planner's rule) together with an x window of more than 36 taps (no ring kernel has one) fell to the two-pass
+    kernels; the long-window accumulator kernel follows the row list instead."""
+    rng = np.random.default_rng(970 + PIXELS.index(pixel))
+    for (sw, sh, dw, dh, filt) in [(864, 24, 96, 12, "lanczos"), (1210, 48, 96, 12, "lanczos"), (2000, 24, 100, 12, "box"), (1536, 40, 64, 10, "lanczos")]:
+        img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8])))
+        got = picha_amd.resizeSync(img, {"width": dw, "height": dh, "filter": filt})
+        name = N.lib().picha_hip_last_kernel().decode()
+        assert name != "twopass", (pixel, sw, sh, dw, dh, filt)
+        assert max_code_diff(got, oracle_resize(img, dw, dh, filt, 1.0)) == 0, (pixel, sw, sh, dw, dh, filt, name)
+
+
+@pytest.mark.parametrize("pixel", PIXELS)
 def test_ring_aliased_tables_on_the_accumulator_kernel_match_oracle(pixel):
     """r03: lanczos and box at even integer scales make the reference's ring one row short (src/resize.cc:52-64): the first tap of
     every output row reads the window's LAST row.  The accumulator kernel follows a row LIST in which that row appears once more
