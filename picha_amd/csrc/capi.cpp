@@ -1821,6 +1821,38 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
         p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
         p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
+        if (acc_long && use_acc && opt_chunks <= 0) {
+            // long windows, small batches (r03, profiles/r03_sweep_long_chunks.txt): LDS holds only 5-13 waves per CU and a thumbnail
+            // row is a handful of waves, so 16 images at 16 rows per chunk leave most of the device idle - and while every
+            // workgroup is resident at once the launch takes as long as ONE wave needs for its chunk plus the window above it:
+            // shorter chunks are faster although each re-resamples that window (16 x 4K -> 320x180 lanczos: 11 chunks 0.32 ms,
+            // 22 chunks 0.20).  Go down to 8 rows per chunk as long as the launch stays within 80 % of what the occupancy
+            // query says is resident.  Beyond one round the time is not monotonic in the chunk count (89-100 % of the queried
+            // residency already takes two rounds; measured optima move by format): the chunk rule above stays.
+            const int resident = acc_kernel_resident_blocks(pixel, p);
+            const long long row_blocks = (long long)n * ((col_waves * 64 + p.long_block - 1) / p.long_block);
+            const double cap = (p.long_block == 256 ? 1.0 : 0.8) * resident;
+            for (int c = std::max(1, d0.height / 8); resident > 0 && c > p.n_chunks; --c) {
+                const int rows = (d0.height + c - 1) / c, nc = (d0.height + rows - 1) / rows;
+                if (row_blocks * nc > cap) continue;
+                p.rows_per_chunk = rows; p.n_chunks = nc;
+                break;
+            }
+            // ... and a launch of one to two such rounds is cut back to one: its second round would be partly idle
+            // (31 x 24 Mpixel rgba -> 300x200 lanczos: 12 chunks 3.03 ms, 11 chunks 1.80)
+            if (resident > 0 && row_blocks * p.n_chunks > cap && row_blocks * p.n_chunks <= 2.0 * cap) {
+                for (int c = p.n_chunks - 1; c >= 1; --c) {
+                    const int rows = (d0.height + c - 1) / c, nc = (d0.height + rows - 1) / rows;
+                    if (row_blocks * nc > cap) continue;
+                    p.rows_per_chunk = rows; p.n_chunks = nc;
+                    break;
+                }
+            }
+            static const bool trace = getenv("PICHA_HIP_TRACE_PLAN") != nullptr;
+            if (trace)
+                fprintf(stderr, "[picha_hip] long-window plan: %d resident workgroups of %d threads, %lld workgroups per chunk row -> %d chunks of %d rows\n",
+                        resident, p.long_block, row_blocks, p.n_chunks, p.rows_per_chunk);
+        }
         // work items (accumulator kernel, windows up to 36 taps)
         const int work_mode = !use_acc || ktaps > 36 ? 0 : opt_work == 3 ? 0 : opt_work > 0 ? (int)opt_work : work_default(n, col_waves, p.n_chunks, true, acc_xch);
         if (work_mode) {
