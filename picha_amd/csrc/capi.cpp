@@ -1818,21 +1818,32 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             const long long by_fill = (8192 + n * col_waves - 1) / (n * col_waves);
             chunks = std::min(chunks, std::max(by_halo, by_fill));
         }
-        chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
+        chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, opt_chunks > 0 ? d0.height : d0.height / 16)));  // a forced count may go down to one row
         p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
         p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
+        if (!acc_long && use_acc && opt_chunks <= 0 && n * col_waves * p.n_chunks < 3000) {
+            // a handful of images (the plain picha.resize call is ONE): at 16 rows per chunk the launch is a few hundred waves on
+            // 256 CUs and takes as long as one wave needs for its rows.  Chunks of down to one row, for about 3000 waves in all
+            // (r03, profiles/r03_sweep_acc_small_batches.txt: one 4K rgba -> 500x281 0.141 -> 0.041 ms, one 1080p rgba -> 300x169
+            // 0.092 -> 0.019; the optimum sat at 2-4 K waves for every format and geometry tried; from ~16 images on nothing changes)
+            const long long c = std::min<long long>(d0.height, (3000 + n * col_waves - 1) / (n * col_waves));
+            if (c > p.n_chunks) {
+                p.rows_per_chunk = (int)((d0.height + c - 1) / c);
+                p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
+            }
+        }
         if (acc_long && use_acc && opt_chunks <= 0) {
             // long windows, small batches (r03, profiles/r03_sweep_long_chunks.txt): LDS holds only 5-13 waves per CU and a thumbnail
             // row is a handful of waves, so 16 images at 16 rows per chunk leave most of the device idle - and while every
             // workgroup is resident at once the launch takes as long as ONE wave needs for its chunk plus the window above it:
             // shorter chunks are faster although each re-resamples that window (16 x 4K -> 320x180 lanczos: 11 chunks 0.32 ms,
-            // 22 chunks 0.20).  Go down to 8 rows per chunk as long as the launch stays within 80 % of what the occupancy
-            // query says is resident.  Beyond one round the time is not monotonic in the chunk count (89-100 % of the queried
+            // 22 chunks 0.20; one image -> 400x225: 28 chunks 0.108 ms, 225 chunks 0.045).  Go down to one row per chunk as long as
+            // the launch stays within 80 % of what the occupancy query says is resident.  Beyond one round the time is not monotonic in the chunk count (89-100 % of the queried
             // residency already takes two rounds; measured optima move by format): the chunk rule above stays.
             const int resident = acc_kernel_resident_blocks(pixel, p);
             const long long row_blocks = (long long)n * ((col_waves * 64 + p.long_block - 1) / p.long_block);
             const double cap = (p.long_block == 256 ? 1.0 : 0.8) * resident;
-            for (int c = std::max(1, d0.height / 8); resident > 0 && c > p.n_chunks; --c) {
+            for (int c = d0.height; resident > 0 && c > p.n_chunks; --c) {
                 const int rows = (d0.height + c - 1) / c, nc = (d0.height + rows - 1) / rows;
                 if (row_blocks * nc > cap) continue;
                 p.rows_per_chunk = rows; p.n_chunks = nc;
