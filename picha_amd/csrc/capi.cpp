@@ -1140,7 +1140,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         const long long by_fill = (8192 + (long long)n * col_waves - 1) / ((long long)n * col_waves);
         chunks = std::min(chunks, std::max(by_halo, by_fill));
     }
-    chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
+    chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, opt_chunks > 0 ? d0.height : d0.height / 16)));
+    // small launches (a single image): chunks of down to one row for about 3000 waves, as for the accumulator kernel
+    if (opt_chunks <= 0 && (long long)n * col_waves * chunks < 3000)
+        chunks = std::max(chunks, std::min<long long>(d0.height, (3000 + (long long)n * col_waves - 1) / ((long long)n * col_waves)));
     p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
     p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
     auto fail_launch = [&](hipError_t e) {
@@ -1317,6 +1320,9 @@ int rows_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, i
         const long long min_rows = (long long)std::ceil(ring / (0.08 * src_rows_per_out));
         chunks = std::min(chunks, std::max<long long>(1, d0.height / std::max<long long>(8, min_rows)));
     }
+    // small launches (a single image is one or two workgroups per chunk): the halo rule above would leave a handful of
+    // workgroups on 256 CUs; chunks of down to one row for about three workgroups per CU (r03, profiles/r03_ab_small_launches.txt)
+    if (opt_chunks <= 0 && blocks_per_chunk * chunks < 768) chunks = std::max(chunks, (768 + blocks_per_chunk - 1) / blocks_per_chunk);
     chunks = std::max<long long>(1, std::min<long long>(chunks, d0.height));
     p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
     p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
