@@ -1554,7 +1554,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 const int rows = std::max(fma ? 20 : 60, (halo * 12 + sy - 1) / sy);
                 chunks = std::max<long long>(chunks, (d0.height + rows - 1) / rows);
             }
-            chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, d0.height / 16)));
+            chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, opt_chunks > 0 ? d0.height : d0.height / 16)));
+            // small launches (a single image): chunks of down to 4 rows for about 3000 waves (profiles/r03_ab_small_launches.txt)
+            if (opt_chunks <= 0 && n * col_waves * chunks < 3000)
+                chunks = std::max(chunks, std::min<long long>(std::max(1, d0.height / 4), (3000 + n * col_waves - 1) / (n * col_waves)));
             p.rows_per_chunk = (int)((d0.height + chunks - 1) / chunks);
             p.n_chunks = (d0.height + p.rows_per_chunk - 1) / p.rows_per_chunk;
             // work items (sym kernel): explicit list with short chunks last, optionally pulled by persistent workgroups
