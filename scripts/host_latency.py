@@ -13,6 +13,7 @@ for (w, h, dw, dh, pix) in [(640, 480, 320, 240, 'rgba'), (3840, 2160, 1920, 108
     for _ in range(n): picha_amd.resizeSync(img, {'width': dw, 'height': dh})
     dt = (time.perf_counter() - t0) / n
     print('resizeSync %dx%d %s -> %dx%d : %.3f ms/call  %.1f Mpix/s (src), PCIe-inclusive' % (w, h, pix, dw, dh, dt * 1e3, w * h / dt / 1e6))
+    for _ in range(3): picha_amd.colorConvertSync(img, {'pixel': 'grey'})
     t0 = time.perf_counter()
     for _ in range(n): picha_amd.colorConvertSync(img, {'pixel': 'grey'})
     dt = (time.perf_counter() - t0) / n
