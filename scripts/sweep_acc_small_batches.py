@@ -8,9 +8,11 @@ torch.cuda.set_device(0)
 lib = N.lib()
 CASES_STREAM = [('rgba', (3840, 2160, 1920, 1080), None), ('rgb', (1920, 1080, 960, 540), None), ('rgba', (640, 480, 320, 240), None), ('grey', (3840, 2160, 1280, 720), None),
                 ('rgba', (3840, 2160, 960, 540), None), ('rgb', (960, 540, 1920, 1080), None), ('rgba', (1920, 1080, 1280, 720), None), ('grey', (3840, 2160, 512, 288), 'lanczos')]
+CASES_SPAN = [('rgb', (960, 540, 1440, 810), None), ('rgba', (1920, 1080, 2560, 1440), None), ('grey', (960, 540, 1000, 563), None), ('rgba', (1280, 720, 1920, 1080), 'lanczos'),
+              ('r16g16b16a16', (960, 540, 1440, 810), None)]
 CASES_ACC = [('rgb', (3840, 2160, 640, 360), None), ('rgba', (3840, 2160, 500, 281), None), ('rgb', (4032, 3024, 800, 600), None),
                                       ('grey', (3840, 2160, 400, 225), 'lanczos'), ('rgba', (1920, 1080, 300, 169), None), ('rgb', (3840, 2160, 1280, 720), 'mitchel')]
-for pixel, (sw, sh, dw, dh), filt in (CASES_STREAM if len(sys.argv) > 1 and sys.argv[1] == 'stream' else CASES_ACC):
+for pixel, (sw, sh, dw, dh), filt in (CASES_STREAM if len(sys.argv) > 1 and sys.argv[1] == 'stream' else CASES_SPAN if len(sys.argv) > 1 and sys.argv[1] == 'span' else CASES_ACC):
     for n in ((1, 2, 4, 8, 16) if len(sys.argv) > 1 else (1, 2, 4, 8, 16, 32, 64)):
         src = DeviceBatch(n, sw, sh, pixel).fill_random(1)
         dst = DeviceBatch(n, dw, dh, pixel)
