@@ -130,7 +130,7 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "acc"        accumulator kernel: 0 = auto, 1 = whenever representable, 2 = never
  *   "acc_p2"     accumulator kernel with two outputs per lane: 0 = auto (measured table), 1 = whenever a shape
  *                exists, 2 = never
- *   "long_block" long-window accumulator kernel (33..128 horizontal taps): threads per workgroup, 0 = auto (most live
+ *   "long_block" long-window accumulator kernel (33..256 horizontal taps): threads per workgroup, 0 = auto (most live
  *                resident waves per CU), 64 / 128 / 192 / 256
  *   "per_lane"   0 = auto, else output columns per lane for the fused kernels (1, 2, 3, 4; 3 only in the
  *                symmetric-table kernel)

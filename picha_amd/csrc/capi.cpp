@@ -1688,7 +1688,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     // 7 waves per CU); the accumulator kernel keeps nacc x channels registers instead.
     constexpr int kAccMinRing = 1;  // measured faster than the span kernel for every ring size it was tried on (profiles/r01_survey_acc_vs_span.txt)
     // no bucket (above 36 taps; 34..36 for odd pixel sizes and 36 for 2- and 6-byte pixels, whose aligned fetch needs room)
-    const bool acc_long = !yr && ataps == 0 && ax->host.taps > 32 && ax->host.taps <= 128;
+    const bool acc_long = !yr && ataps == 0 && ax->host.taps > 32 && ax->host.taps <= kAccLongMaxTaps;
     if (acc_long) {  // long windows: LDS-resident weights, tap count padded to half a load segment
         const int half = acc_long_segment(kBytes[pixel]) / 2;
         ataps = (ax->host.taps + half - 1) / half * half;

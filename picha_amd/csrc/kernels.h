@@ -109,13 +109,16 @@ struct FusedParams {
     int epi_on, epi_pixel;
     float epi_r, epi_g, epi_b;
 };
-// Accumulator kernel: instantiations exist for x tap buckets >= 4 and nacc in {4, 6}.  Windows of 37..128 taps go to the
+// Accumulator kernel: instantiations exist for x tap buckets >= 4 and nacc in {4, 6}.  Windows of 33..256 taps (kAccLongMaxTaps) go to the
 // long-window variant, which walks the window in segments of acc_long_segment() pixels (64..96 bytes: measured best —
 // 8-pixel segments cost +35 %, 32-pixel segments of rgba +19 %, of grey -27 %) plus an optional half segment at the end,
 // so its tap count is a multiple of half a segment.
 constexpr int acc_long_segment(int bytes_per_pixel) { return bytes_per_pixel <= 3 ? 32 : (bytes_per_pixel <= 6 ? 16 : 8); }
 // ... with this many segment buffers per wave (r03, profiles/r03_ab_acc_long.txt: four in flight are 0-10 % faster than two for
 // pixels of up to 4 bytes, 0-15 % slower for 8-byte pixels)
+// Longest window of the long-window kernel: 256 taps = 64 KB of LDS weights per wave, two single-wave workgroups per CU (r03: was 128;
+// beyond it the two-pass kernels remain)
+constexpr int kAccLongMaxTaps = 256;
 constexpr int acc_long_bufs(int bytes_per_pixel) { return bytes_per_pixel <= 4 ? 4 : 2; }
 bool acc_supported(int pixel, int x_taps_bucket, int nacc);
 bool acc_p2_supported(int pixel, int step, int taps, int nacc);  // two outputs per lane: window of the second `step` pixels after the first

@@ -262,7 +262,7 @@ bool acc_supported(int pixel, int x_taps_bucket, int nacc) {
     if (pixel < 0 || pixel > 7 || (nacc != 4 && nacc != 6)) return false;
     if (x_taps_bucket > 36) {  // resize_acc_long_kernel: multiples of half a segment
         const int half = acc_long_segment(pixel_channels(pixel) * (pixel_is16(pixel) ? 2 : 1)) / 2;
-        return x_taps_bucket % half == 0 && x_taps_bucket <= 128;
+        return x_taps_bucket % half == 0 && x_taps_bucket <= kAccLongMaxTaps + half;
     }
     switch (x_taps_bucket) {
     case 4: case 5: case 6: case 7: case 8: case 10: case 12: case 14: case 16: case 18: case 20: case 22: case 24: case 28: case 32: case 36:

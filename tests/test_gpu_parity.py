@@ -798,7 +798,8 @@ def test_long_window_accumulator_kernel(pixel):
     rng = np.random.default_rng(900 + PIXELS.index(pixel))
     for (sw, sh, dw, dh, filt, fscale) in [(2000, 90, 100, 30, "cubic", 0.70),      # 20x: 57 taps -> 64
                                              (1203, 77, 97, 11, "lanczos", 1.0),      # 12.4x, 2-lobe: 51 taps; y 7x
-                                             (3001, 40, 64, 9, "mitchel", 1.0),       # 47x: > 128 taps -> two-pass
+                                             (3001, 40, 64, 9, "mitchel", 1.0),       # 47x: 188 taps (r03: the long-window kernel goes to 256)
+                                             (6002, 24, 64, 9, "mitchel", 1.0),       # 94x: > 256 taps -> two-pass
                                              (640, 33, 40, 8, "triangle", 1.0)]:      # 16x triangle: 33 taps (short kernel)
         img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8])))   # multiples of 8: the widest format's alignment rule
         opts = {"width": dw, "height": dh}
@@ -810,9 +811,9 @@ def test_long_window_accumulator_kernel(pixel):
             got = picha_amd.resizeSync(img, opts)
             name = N.lib().picha_hip_last_kernel().decode()
             assert max_code_diff(got, exp) == 0, (pixel, sw, sh, dw, dh, filt, chunks, name)
-            if sw in (2000, 1203):
+            if sw in (2000, 1203, 3001):
                 assert name.startswith("resize_acc_long<ch%d" % N.PIXEL_CHANNELS[pixel]), name
-            if sw == 3001:
+            if sw == 6002:
                 assert name == "twopass", name
         set_opt("row_chunks", 0)
         set_opt("numerics", 1)
