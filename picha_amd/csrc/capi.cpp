@@ -926,6 +926,16 @@ int get_yrange(DeviceCtx *ctx, DeviceAxis *ay, const int32_t **out) {
 
 long g_opt_run = 0;   // run kernel (periodic tap tables, kernels_run.hip): 0 auto, 1 whenever it applies, 2 never
 long g_opt_run_round = 0;  // its window offsets inside a period: 0 auto (the shorter window), 1 rounded down, 2 rounded up
+long g_opt_run_xch = 0;    // its neighbour-exchange form (dword-sized pixels, integer scales; r04): 0 auto, 1 wherever instantiated, 2 never
+long g_opt_run_ws = 0;     // weights of one phase of the period in SGPRs (r04): 0 auto, 1 wherever instantiated, 2 never
+long g_opt_run_phase = 0;  // time-phased stores of the neighbour-exchange run kernel (r04): 0 auto, -1 off, n > 0: phases of 2^n ticks of the 100 MHz counter (12 = 41 us)
+
+// where the neighbour-exchange run kernel is the default: cfg5's shape (r16g16b16a16 at 4x, 15 taps) — measured r04 against the
+// r03 accumulator form (lane-resident weights, 157 VGPRs, 3 waves per SIMD): profiles/r04_ab_run_xch.txt
+bool run_xch_preferred(int pixel, int period_px, int taps, int per_lane, int fma) {
+    (void)fma;
+    return pixel == PICHA_R16G16B16A16 && period_px == 4 && taps == 15 && per_lane == 2;
+}
 
 // Run kernel for one equal-geometry group: downscales whose x scale is a ratio of small integers with a long window.
 // *used = false: not applicable, the caller goes on with the other kernels.
@@ -933,9 +943,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     *used = false;
     const picha_image &s0 = src[0], &d0 = dst[0];
     const int pixel = s0.pixel;
-    long opt_run, opt_run_round, opt_numerics, opt_chunks, opt_per_lane, opt_work, opt_work_tail, opt_work_tail_div, opt_bw;
+    long opt_run, opt_run_round, opt_numerics, opt_chunks, opt_per_lane, opt_work, opt_work_tail, opt_work_tail_div, opt_bw, opt_run_xch, opt_run_ws, opt_run_phase;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
+        opt_run_xch = g_opt_run_xch; opt_run_ws = g_opt_run_ws; opt_run_phase = g_opt_run_phase;
         opt_run = g_opt_run; opt_run_round = g_opt_run_round; opt_numerics = g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
         opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
         opt_bw = g_opt_block_waves;
@@ -1009,6 +1020,20 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     static const int order1[] = {4, 8, 2}, order2[] = {2, 4, 8};
     // upscales (r03, profiles/r03_ab_up_kernel.txt): the longest run that is instantiated
     static const int order_up[] = {8, 4, 2};
+    // neighbour-exchange form (r04): dword-sized pixels at integer scales; the canonical window starts -x_base pixels before the
+    // lane's own; the clipped columns are recomputed from the image (no stash)
+    int xhl = -1;
+    if (!up && !ring_mode && opt_run_xch != 2 && kBytes[pixel] % 4 == 0 && period == 1) {
+        int xb = 0;
+        const int tx = run_table_taps(ax->host, period, period_px, 0, &xb);
+        for (int pl0 : order2) {
+            const int pl = opt_per_lane > 0 ? (int)opt_per_lane : pl0;
+            if (tx <= 0 || xb > 0 || !run_kernel_supported(pixel, period, period_px, tx, pl, nacc, 0, -xb, 0)) continue;
+            if (opt_run_xch == 0 && opt_run != 1 && !run_xch_preferred(pixel, period_px, tx, pl, fma)) continue;
+            per_lane = pl; ktaps = tx; ceil_off = 0; xhl = -xb;
+            break;
+        }
+    }
     for (int k = 0; k < 2 && !per_lane; ++k) {
         const int c = (tx_of[1] > 0 && tx_of[1] < tx_of[0]) ? 1 - k : k;   // the shorter window first
         if (tx_of[c] <= 0 || (period == 1 && c == 1) || (opt_run_round != 0 && opt_run_round != c + 1)) continue;
@@ -1028,7 +1053,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // measured on 128-256 images); the 21-tap 7.5x shape was a tie for greya and needs >= 192 images for grey
     const int ch = kChannels[pixel];
     const bool short_ok = period_px == 15 ? (ch == 1 && n >= 192) : (ch <= 2 && n >= 96);
-    if (!ring_mode && opt_run == 0 && ktaps < 26 && !short_ok) return PICHA_OK;
+    if (!ring_mode && xhl < 0 && opt_run == 0 && ktaps < 26 && !short_ok) return PICHA_OK;
+    // one phase's weights in SGPRs (r04): where instantiated — the 7.5x shapes, whose 2 x 30 lane-uniform weight registers held the
+    // kernel at 3 waves per SIMD (profiles/r04_ab_run_ws.txt)
+    const int wsgpr = !ring_mode && xhl < 0 && opt_run_ws != 2 && run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -1, 1) ? 1 : 0;
     const DeviceAxis::RunTable *rt = nullptr;
     rc = get_runtable(ctx, ax, period, period_px, ceil_off, ktaps, wmode, is16, &rt);
     if (rc) return rc;
@@ -1037,8 +1065,9 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // edge columns: recomputed by resize_edges_kernel from a stash of the raw dwords of the two lanes that hold them (kernels_run.hip)
     const int x_groups = (d0.width + per_lane - 1) / per_lane;
     const bool has_edges = rt->c0 > 0 || rt->c1 < d0.width;
+    if (xhl >= 0 && rt->x_base != -xhl) return PICHA_OK;
     int stash_words = 0, stash_org[2] = {0, 0};
-    if (has_edges) {
+    if (has_edges && xhl < 0) {
         const int bpp = kBytes[pixel];
         const int span = ((per_lane - 1) / period) * period_px + (((per_lane - 1) % period) * period_px + ceil_off * (period - 1)) / period + ktaps;  // RunCfg::SPAN
         stash_words = bpp % 4 == 0 ? span * bpp / 4 : (span * bpp + 3) / 4 + 1;                                        // RunCfg::NW
@@ -1103,7 +1132,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         if (stash_used) r2 = temp_release(ctx->scratch, s);
         return r1 ? r1 : r2;
     };
-    if (has_edges && opt_run != 3) {
+    if (has_edges && opt_run != 3 && xhl >= 0) p.edge_image = 1;
+    if (has_edges && opt_run != 3 && xhl < 0) {
         const size_t bytes = (size_t)n * 2 * s0.height * stash_words * 4;
         if (bytes >= ((size_t)1 << 32)) { (void)release_temps(); return PICHA_OK; }
         if (!temp_lock.owns_lock()) temp_lock.lock();
@@ -1120,6 +1150,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     p.x_groups = x_groups;
     p.x_canon = rt->canon;
     p.fma = fma;
+    p.xch = xhl >= 0 ? 1 : 0; p.wsgpr = wsgpr;
+    // time-phased stores: where the stores are a thin trickle beside the reads (>= 3 source rows per output row) and the launch is long
+    // enough for several phases; 2^12 ticks = 41 us measured best on cfg5 (profiles/r04_ab_run_phase.txt)
+    if (xhl >= 0 && opt_run_phase >= 0) p.phase_shift = opt_run_phase > 0 ? (int)std::min(20L, opt_run_phase) : (s0.height >= 3 * d0.height && (long long)n * s0.height >= 20000 ? 12 : 0);
     if (ring_mode) { p.yrow_range = up_range; p.y_left = ay->left; p.y_info = ay->y_info; p.ring_rows = ring_rows; }
     else { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; }
     p.cx0 = rt->c0; p.cx1 = rt->c1;
@@ -1195,7 +1229,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
             done += m;
         }
     }
-    if (p.stash) {
+    if (p.stash || p.edge_image) {
         static thread_local char name[192];
         snprintf(name, sizeof name, "%s + resize_edges<%d columns>", g_last_kernel ? g_last_kernel : "", p.cx0 + (d0.width - p.cx1));
         g_last_kernel = name;
@@ -2270,6 +2304,9 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "block_waves") == 0) { g_opt_block_waves = value; return PICHA_OK; }
     if (strcmp(key, "sym_sync") == 0) { g_opt_sym_sync = value; return PICHA_OK; }
     if (strcmp(key, "xch") == 0) { g_opt_xch = value; return PICHA_OK; }
+    if (strcmp(key, "run_xch") == 0) { g_opt_run_xch = value; return PICHA_OK; }
+    if (strcmp(key, "run_ws") == 0) { g_opt_run_ws = value; return PICHA_OK; }
+    if (strcmp(key, "run_phase") == 0) { g_opt_run_phase = value; return PICHA_OK; }
     if (strcmp(key, "up") == 0) { g_opt_up = value; return PICHA_OK; }
     if (strcmp(key, "work") == 0) { g_opt_work = value; return PICHA_OK; }
     if (strcmp(key, "work_tail") == 0) { g_opt_work_tail = value; return PICHA_OK; }
@@ -2301,6 +2338,9 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "block_waves") == 0) return g_opt_block_waves;
     if (strcmp(key, "sym_sync") == 0) return g_opt_sym_sync;
     if (strcmp(key, "xch") == 0) return g_opt_xch;
+    if (strcmp(key, "run_xch") == 0) return g_opt_run_xch;
+    if (strcmp(key, "run_ws") == 0) return g_opt_run_ws;
+    if (strcmp(key, "run_phase") == 0) return g_opt_run_phase;
     if (strcmp(key, "up") == 0) return g_opt_up;
     if (strcmp(key, "work") == 0) return g_opt_work;
     if (strcmp(key, "work_tail") == 0) return g_opt_work_tail;

@@ -273,8 +273,13 @@ struct RunParams {
     const int32_t *y_left;  // [dst_h] (resize_ring_kernel)
     const int4 *y_info;     // [dst_h] {., need, ., .}: the last source row the reference has resampled when it produces the row
     int ring_rows;          // resize_ring_kernel: rows of its register ring (the reference's ring where the table is aliased)
+    // r04 forms of the run kernel (kernels_run.hip)
+    int xch;         // 1: neighbour exchange — a lane loads only its own (x_per_lane / period) * period_px pixels (dword-sized pixels; x_base <= 0 is minus the window pixels in front of them)
+    int wsgpr;       // phases of the period whose weights stay in SGPRs (0 .. period)
+    int edge_image;  // 1: resize_edges_kernel reads the edge columns' windows from the image, not from a stash
+    int phase_shift; // > 0 (neighbour-exchange shapes): time-phased stores — finished rows wait in registers until s_memrealtime >> phase_shift changes
 };
-bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc, int off_ceil);
+bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc, int off_ceil, int xhl = -1, int wsgpr = 0);
 hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s, const char **kernel_name);
 // ring-in-registers kernel (integer upscales: period = the factor, period_px = 1, ring 4; ring-aliased downscales: ring = the
 // reference's): yrow_rec unused; yrow_range: per output row {first source row needed by it or any later row, last row so far}

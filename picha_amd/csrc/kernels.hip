@@ -32,7 +32,7 @@ PICHA_DECL_SYM(4) PICHA_DECL_SYM(5) PICHA_DECL_SYM(6) PICHA_DECL_SYM(7)
 #undef PICHA_DECL_SYM
 // defined in kernels_run.hip, one translation unit per pixel format
 #define PICHA_DECL_RUN(N)                                                                \
-    bool run_supported_pixel##N(int q, int px, int tx, int per_lane, int nacc, int rc);   \
+    bool run_supported_pixel##N(int q, int px, int tx, int per_lane, int nacc, int rc, int xhl, int ws);   \
     hipError_t launch_run_pixel##N(const RunParams &p, hipStream_t s, const char **name); \
     hipError_t launch_edges_pixel##N(const RunParams &p, hipStream_t s); \
     bool up_supported_pixel##N(int q, int px, int tx, int per_lane, int rc, int ring, int ty); \
@@ -40,9 +40,9 @@ PICHA_DECL_SYM(4) PICHA_DECL_SYM(5) PICHA_DECL_SYM(6) PICHA_DECL_SYM(7)
 PICHA_DECL_RUN(0) PICHA_DECL_RUN(1) PICHA_DECL_RUN(2) PICHA_DECL_RUN(3)
 PICHA_DECL_RUN(4) PICHA_DECL_RUN(5) PICHA_DECL_RUN(6) PICHA_DECL_RUN(7)
 #undef PICHA_DECL_RUN
-bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc, int off_ceil) {
+bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc, int off_ceil, int xhl, int wsgpr) {
     switch (pixel) {
-#define PICHA_CASE(N) case N: return run_supported_pixel##N(period, period_px, taps, per_lane, nacc, off_ceil);
+#define PICHA_CASE(N) case N: return run_supported_pixel##N(period, period_px, taps, per_lane, nacc, off_ceil, xhl, wsgpr);
     PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
 #undef PICHA_CASE
     }

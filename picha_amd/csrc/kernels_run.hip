@@ -20,8 +20,17 @@
 // (edge_pass below; how the other forms of this step measured: profiles/r03_ab_run_kernel.txt).
 #define PICHA_SPAN_ONLY 1
 #include "kernels_impl.inc"
+#include <cstring>
 #ifndef PICHA_RUN_NB
 #define PICHA_RUN_NB 3
+#endif
+#ifndef PICHA_RUN_XNB
+#define PICHA_RUN_XNB 2   // row buffers of the neighbour-exchange form
+#endif
+// measurement builds only (scripts/r04_ablate.sh; results are wrong by construction): 1 = loads and stores without the arithmetic,
+// 2 = arithmetic and stores without the loads in the loop, 3 = no halo exchange (the lane's own pixels stand in for its neighbours')
+#ifndef PICHA_RUN_ABLATE
+#define PICHA_RUN_ABLATE 0
 #endif
 
 namespace picha_hip {
@@ -176,18 +185,64 @@ __global__ __launch_bounds__(64) void resize_edges_kernel(RunParams p) {
     if (y0 >= y1 || na <= 0) return;
     uint8_t *dbase = uniform_ptr(p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch);
     const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
+    if (p.edge_image) {
+        // (r04) no stash: the windows come from the image itself.  The descriptor starts on the dword at or below the image and ends on
+        // the one at or above its last byte; a window that runs past its row meets zero weights (or, past the image, reads 0)
+        const uint8_t *sbase = uniform_ptr(p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch);
+        const int sadj = int(reinterpret_cast<uintptr_t>(sbase) & 3u);
+        const __amdgpu_buffer_rsrc_t img_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(sbase) - sadj, 0, (p.src_bytes + sadj + 3u) & ~3u, 0x00020000);
+        edge_pass<CH, S16, TXE>(p, img_rs, p.src_stride, -sadj, dst_rs, lane, edge_lds, xa0, na, y0, y1);
+        return;
+    }
     const unsigned st_stride = unsigned(p.stash_words) * 4u, st_bytes = st_stride * unsigned(p.src_h);
     const __amdgpu_buffer_rsrc_t stash_rs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<uint8_t *>(p.stash) + (size_t)((p.stash_img0 + img) * 2 + side) * st_bytes, 0, st_bytes, 0x00020000);
     edge_pass<CH, S16, TXE>(p, stash_rs, int(st_stride), p.stash_org[side], dst_rs, lane, edge_lds, xa0, na, y0, y1);
 }
 
-template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC, bool FMA, int RC = 0>
+// XHL >= 0 (r04): NEIGHBOUR EXCHANGE for dword-sized pixels.  A lane loads only the (P / Q) * PX pixels it owns — the wave reads one
+// contiguous run per row, no byte is requested twice (cfg5's plain form asks for every source byte 4.75 times and is bound by the L1's
+// request rate, profiles/r03_cfg5_before_rocprofv3_summary.txt) — and takes the XHL pixels in front of them from lane - 1 and the
+// SPAN - OWN - XHL behind them from lane + 1 with DPP wave shifts of the RAW dwords (before conversion: products and sums are the
+// reference's, bit for bit).  What lanes 0 and 63 miss — the wave's own halo, NH <= 64 dwords — is loaded ONE dword per lane with
+// the row (one more register per row buffer, where the r03 accumulator form kept 12 in all 64 lanes for what two of them use) and
+// handed to the two edge lanes through 256 bytes of wave-private LDS when the row is resampled.  The columns an image edge clips
+// come out with the canonical weights here and are overwritten by resize_edges_kernel reading the IMAGE (no stash: p.edge_image).
+// WS (r04): the weights of the last WS phases of the period stay in SGPRs (an SGPR operand costs a product 2.35 instead of 1.38
+// issue ticks, profiles/r01_ubench_valu_issue_rates.txt, but Q x TX lane-uniform VGPRs are what kept cfg3b at 3 waves per SIMD).
+template <int CH, bool S16, int Q, int PX, int TX, int P, int XHL> struct RunXch {
+    static constexpr int BPP = CH * Sample<S16>::kBytes;
+    static constexpr int DPX = BPP / 4;
+    static constexpr int OWN = (P / Q) * PX;                       // pixels a lane loads itself
+    static constexpr int SPAN = run_off(Q, PX, P - 1, 0) + TX;
+    static constexpr int HL = XHL < 0 ? 0 : XHL, HR = SPAN - OWN - HL;
+    static constexpr int NOWN = OWN * DPX, NHL = HL * DPX, NHR = HR * DPX, NH = NHL + NHR;
+    static constexpr bool OK = BPP % 4 == 0 && HR >= 0 && HL <= OWN && HR <= OWN && NH <= kWave;
+};
+// PH (r04): TIME-PHASED STORES.  A finished output row is packed and kept in registers (up to kPhaseRows rows per lane); the wave stores
+// what it holds when the chip-wide 100 MHz counter (s_memrealtime) crosses a multiple of 2^phase_shift ticks — every wave of
+// every workgroup in the same few microseconds — or when it holds kPhaseRows rows, or at the end of its chunk.  Why: in cfg5's march the
+// stores are 6 % of the bytes but cost 20-30 % of the time (profiles/r04_ubench_march_pattern.txt: the read pattern alone streams at
+// 6.1 TB/s, with the stores at 4.9-5.7 depending on where the destination was allocated; even 0.7 % of stores cost 10 %): a thin,
+// steady trickle of writes makes every HBM channel turn its bus around for a line or two at a time.  Bunched into chip-wide bursts
+// every ~40 us the same bytes cost half as much.  (At cfg2's 4:1 read:write ratio the write queues are never thin and phasing loses.)
+#ifndef PICHA_RUN_PHASE_ROWS
+#define PICHA_RUN_PHASE_ROWS 8
+#endif
+constexpr int kPhaseRows = PICHA_RUN_PHASE_ROWS;
+template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC, bool FMA, int RC = 0, int XHL = -1, int WS = 0, int PH = 0>
 __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     using C = RunCfg<CH, S16, Q, PX, TX, P, RC>;
+    using X = RunXch<CH, S16, Q, PX, TX, P, XHL>;
+    constexpr bool XCH = XHL >= 0;
     static_assert(P % Q == 0, "a lane owns whole periods");
-    constexpr int NRAW = C::NW;
-    constexpr int NB = NRAW <= 16 ? PICHA_RUN_NB : 2;  // row buffers
+    static_assert(!XCH || (X::OK && RC == 0), "neighbour exchange: dword pixels, halo within one lane's pixels");
+    static_assert(WS >= 0 && WS <= Q, "phases with scalar weights");
+    static_assert(!PH || C::WORDS, "phased stores: dword-sized pixels");
+    constexpr int ODW = PH ? P * (C::BPP / 4) : 1;   // dwords of a lane's packed output row
+    constexpr int NRAW = XCH ? X::NOWN + 1 : C::NW;
+    constexpr int NB = XCH ? PICHA_RUN_XNB : (NRAW <= 16 ? PICHA_RUN_NB : 2);  // row buffers
+    PICHA_PROBE_BEGIN
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
@@ -214,11 +269,22 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
 #pragma unroll
     for (int q = 0; q < Q; ++q)
 #pragma unroll
-        for (int j = 0; j < TX; ++j) asm("v_mov_b32 %0, %1" : "=v"(wx[q][j]) : "s"(wbits[q * TX + j]));
+        for (int j = 0; j < TX; ++j) {
+            if (q < Q - WS) asm("v_mov_b32 %0, %1" : "=v"(wx[q][j]) : "s"(wbits[q * TX + j]));
+            else wx[q][j] = __int_as_float(wbits[q * TX + j]);   // stays scalar: an SGPR operand of its products
+        }
     // the lane's window starts at x_base + PX * (x0 / Q): x0 is a multiple of P, P of Q
-    const int32_t lane_off = (p.x_base + (grp0 + lane) * ((P / Q) * PX)) * C::BPP + sadj;
+    // (neighbour exchange: the lane's OWN pixels, XHL pixels into the window; x_base == -XHL is host-checked)
+    const int32_t lane_off = XCH ? (grp0 + lane) * X::OWN * C::BPP : (p.x_base + (grp0 + lane) * ((P / Q) * PX)) * C::BPP + sadj;
     // a window that starts before the image (left-most lane) must not wrap a merged load in row 0
-    const bool careful = __any(lane_off < 0);
+    const bool careful = !XCH && __any(lane_off < 0);
+    // neighbour exchange: lane k < NHL fetches dword k of the NHL dwords in front of the wave's run, lane NHL + k dword k of the NHR
+    // behind it (the other lanes repeat the last one); in front of the image the offset wraps and the load reads 0 (row 0) or the
+    // end of the previous row: only clipped columns see it, and resize_edges_kernel overwrites those
+    const int32_t halo_k = min(lane, X::NH - 1);
+    const int32_t halo_off = halo_k < X::NHL ? grp0 * X::OWN * C::BPP - X::NHL * 4 + 4 * halo_k
+                                             : (grp0 + kWave) * X::OWN * C::BPP + 4 * (halo_k - X::NHL);
+    __shared__ uint32_t halo_lds[XCH ? 4 * kWave : 1];
 
     const_i32_ptr yrange = (const_i32_ptr)(p.yrow_range);
     const_i32_ptr yrec = (const_i32_ptr)(p.yrow_rec);
@@ -237,13 +303,26 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     // (clamped dword by dword, load_span<.., true>); the loop's own loads are rows >= 1, where a negative lane offset lands in
     // the previous row: one merged, branch-free load sequence — a second load path inside the loop made the compiler wait for
     // the prefetch it had just issued.
+    auto load_row = [&](uint32_t (&t)[NRAW], int row) __attribute__((always_inline)) {
+        if constexpr (XCH) {
+            const uint32_t off = uint32_t(row * p.src_stride + lane_off);
+#pragma unroll
+            for (int k = 0; k < X::NOWN; ++k) t[k] = __builtin_amdgcn_raw_buffer_load_b32(src_rs, off + 4 * k, 0, 0);
+            t[X::NOWN] = __builtin_amdgcn_raw_buffer_load_b32(src_rs, uint32_t(row * p.src_stride + halo_off), 0, 0);
+        } else {
+            load_span<C, false>(src_rs, row * p.src_stride + lane_off, t);
+        }
+    };
     uint32_t raw[NB][NRAW];
 #pragma unroll
     for (int k = 0; k < NB - 1; ++k) {
         const int row = min(r0 + k, r1);
-        const int32_t off = row * p.src_stride + lane_off;
-        if (careful && row <= 0) load_span<C, true>(src_rs, off, raw[k]);
-        else load_span<C, false>(src_rs, off, raw[k]);
+        if constexpr (XCH) { load_row(raw[k], row); }
+        else {
+            const int32_t off = row * p.src_stride + lane_off;
+            if (careful && row <= 0) load_span<C, true>(src_rs, off, raw[k]);
+            else load_span<C, false>(src_rs, off, raw[k]);
+        }
     }
 
     // The lanes that hold the image's first / last columns keep their raw dwords of every row for resize_edges_kernel: into a
@@ -289,19 +368,77 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
             __builtin_amdgcn_wave_barrier();
         }
     };
+    uint32_t obuf[PH ? kPhaseRows : 1][ODW];
+    int nbuf = 0, first_y = 0;   // wave-uniform
+    [[maybe_unused]] unsigned phase = PH ? unsigned(__builtin_amdgcn_s_memrealtime() >> p.phase_shift) : 0u;
+    auto flush_outputs = [&]() __attribute__((always_inline)) {
+        if constexpr (PH) {
+#pragma unroll
+            for (int q = 0; q < kPhaseRows; ++q) {
+                if (q < nbuf) {
+                    const uint32_t doff = uint32_t((first_y + q) * p.dst_stride + x0 * C::BPP);
+                    if (x0 + P <= p.dst_w) store_dwords<ODW, kStoreNT>(dst_rs, doff, obuf[q]);
+                    else {
+#pragma unroll
+                        for (int o = 0; o < P; ++o)
+                            if (x0 + o < p.dst_w) store_dwords<ODW / P, kStoreNT>(dst_rs, doff + o * C::BPP, &obuf[q][o * (ODW / P)]);
+                    }
+                }
+            }
+            nbuf = 0;
+        }
+    };
     auto process_row = [&](uint32_t (&cur)[NRAW], int row) __attribute__((always_inline)) {
-        if (st_wave && row <= r1) stash_row(cur, row);  // wave-uniform
+        if constexpr (!XCH) {
+            if (st_wave && row <= r1) stash_row(cur, row);  // wave-uniform
+        }
         int rec[2 * NACC];
 #pragma unroll
         for (int t = 0; t < 2 * NACC; ++t) rec[t] = yrec[(size_t)row * (2 * NACC) + t];
         // ---- horizontal pass (src/resize.cc:110-117): every window pixel converted once, used by all outputs it is a tap of ----
         float h[P][CH];
-        uint32_t win[C::BROT ? C::NWIN : 1];
+#if PICHA_RUN_ABLATE == 1
+        {
+            uint32_t x = 0;
+#pragma unroll
+            for (int k = 0; k < NRAW; ++k) x ^= cur[k];
+#pragma unroll
+            for (int o = 0; o < P; ++o)
+#pragma unroll
+                for (int c = 0; c < CH; ++c) h[o][c] = __uint_as_float(x & 0x3fffffffu);
+        }
+#else
+        uint32_t win[XCH ? C::NW : (C::BROT ? C::NWIN : 1)];
         if constexpr (C::BROT) rotate_span<C>(cur, uint32_t(min(row, r1) * p.src_stride + lane_off) & 3u, win);
+        if constexpr (XCH && PICHA_RUN_ABLATE == 3) {
+#pragma unroll
+            for (int k = 0; k < C::NW; ++k) win[k] = cur[k % X::NOWN];
+        } else if constexpr (XCH) {
+            // the wave's halo: lane k wrote dword k; every lane reads all of it back (same address in all lanes: a broadcast), lanes 0 /
+            // 63 keep it where the wave shift has no source lane (a DPP move leaves its destination alone there)
+            uint32_t *hl = halo_lds + wave * kWave;
+            hl[lane] = cur[X::NOWN];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            uint32_t hb[X::NH > 0 ? X::NH : 1];
+#pragma unroll
+            for (int k = 0; k < X::NH; ++k) hb[k] = hl[k];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int k = 0; k < X::NHL; ++k)
+                win[k] = __builtin_amdgcn_update_dpp(hb[k], cur[X::NOWN - X::NHL + k], kDppWaveShr1, 0xf, 0xf, false);
+#pragma unroll
+            for (int k = 0; k < X::NOWN; ++k) win[X::NHL + k] = cur[k];
+#pragma unroll
+            for (int k = 0; k < X::NHR; ++k)
+                win[X::NHL + X::NOWN + k] = __builtin_amdgcn_update_dpp(hb[X::NHL + k], cur[k], kDppWaveShl1, 0xf, 0xf, false);
+        }
 #pragma unroll
         for (int q = 0; q < C::SPAN; ++q) {
             float u[CH];
-            if constexpr (C::BROT) unpack_span_px<C, CH, S16, FMA>(win, q, u);
+            if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, q, u);
             else unpack_span_px<C, CH, S16, FMA>(cur, q, u);
 #pragma unroll
             for (int o = 0; o < P; ++o) {
@@ -316,7 +453,14 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
                 }
             }
         }
+#endif
         // ---- fold the row into the pending output rows (src/resize.cc:125-129) ----
+#if PICHA_RUN_ABLATE == 1
+#pragma unroll
+        for (int o = 0; o < P; ++o)
+#pragma unroll
+            for (int c = 0; c < CH; ++c) acc[0][o][c] = h[o][c];
+#else
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
             float w;
@@ -329,17 +473,47 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
                     else acc[a][o][c] = acc[a][o][c] + w * h[o][c];
                 }
         }
+#endif
         // ---- output rows whose window ends with this source row: pack, store (whole dwords: host-checked alignment), clear ----
 #pragma unroll
         for (int a = 0; a < NACC; ++a) {
             const int y = rec[NACC + a];
             if (y >= 0) {  // wave-uniform
-                if (y >= y0 && y < y1) store_lane_outputs<C, CH, S16, P, FMA>(acc[a], dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
+                if constexpr (PH) {
+                    if (y >= y0 && y < y1) {   // pack now, store with the next burst (rows of a chunk complete in ascending order)
+                        uint32_t pk[ODW];
+#pragma unroll
+                        for (int o = 0; o < P; ++o) {
+                            uint32_t t2[2];
+                            pack_px_words<CH, S16, FMA>(acc[a][o], t2);
+                            pk[o * (ODW / P)] = t2[0];
+                            if constexpr (ODW / P == 2) pk[o * 2 + 1] = t2[1];
+                        }
+                        // (several rows can complete with one source row — at the bottom edge every clipped window ends with the last
+                        // row — so the buffer may fill up here; rows held are consecutive by construction, checked all the same)
+                        if (nbuf == kPhaseRows || (nbuf > 0 && y != first_y + nbuf)) flush_outputs();
+                        if (nbuf == 0) first_y = y;
+#pragma unroll
+                        for (int q = 0; q < kPhaseRows; ++q)
+                            if (nbuf == q) {
+#pragma unroll
+                                for (int k = 0; k < ODW; ++k) obuf[q][k] = pk[k];
+                            }
+                        ++nbuf;
+                    }
+                } else {
+                    if (y >= y0 && y < y1) store_lane_outputs<C, CH, S16, P, FMA>(acc[PICHA_RUN_ABLATE == 1 ? 0 : a], dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
+                }
 #pragma unroll
                 for (int o = 0; o < P; ++o)
 #pragma unroll
                     for (int c = 0; c < CH; ++c) acc[a][o][c] = 0.0f;
             }
+        }
+        if constexpr (PH) {
+            const unsigned ph = unsigned(__builtin_amdgcn_s_memrealtime() >> p.phase_shift);
+            if (nbuf == kPhaseRows || (nbuf > 0 && ph != phase)) flush_outputs();
+            phase = ph;
         }
     };
 
@@ -348,14 +522,18 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     for (int r = r0; r <= r1; r += NB) {
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
-            load_span<C, false>(src_rs, max(1, min(r + k + NB - 1, r1)) * p.src_stride + lane_off, raw[(k + NB - 1) % NB]);
+#if PICHA_RUN_ABLATE != 2
+            load_row(raw[(k + NB - 1) % NB], max(XCH ? 0 : 1, min(r + k + NB - 1, r1)));
+#endif
             process_row(raw[k], r + k);
         }
     }
+    flush_outputs();
     };  // run_item
     run_work_items(p.work, [&](int &bx, int &y0, int &y1, int &img) __attribute__((always_inline)) {
         bx = blockIdx.x; y0 = blockIdx.y * p.rows_per_chunk; y1 = min(p.dst_h, y0 + p.rows_per_chunk); img = blockIdx.z;
     }, run_item);
+    PICHA_PROBE_END
 }
 
 // compile-time helpers of resize_ring_kernel: call f(integral_constant<i>) for the run-time i in [0, N) / for every i in [0, N)
@@ -572,10 +750,10 @@ hipError_t launch_ring_t(const RunParams &p, hipStream_t s, const char **name) {
     return hipGetLastError();
 }
 
-template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC, int RC>
+template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC, int RC, int XHL = -1, int WS = 0, int PH = 0>
 hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
-    const void *k = p.fma ? reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true, RC>)
-                          : reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false, RC>);
+    const void *k = p.fma ? reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true, RC, XHL, WS, PH>)
+                          : reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false, RC, XHL, WS, PH>);
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 4;
     const size_t lds = p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, Q, PX, TX, P, RC>::NW + 3) / 4 * 4) : 0;   // the stash staging of the edge lanes
     if (p.resident_query) {
@@ -588,10 +766,14 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
     }
     dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
     if (p.work.items) grid = dim3(p.work.queue ? (unsigned)p.n_chunks : 8u * (unsigned)p.work.items_per_xcd, 1, 1);
-    if (p.fma) resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true, RC><<<grid, 64 * bw, lds, s>>>(p);
-    else resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false, RC><<<grid, 64 * bw, lds, s>>>(p);
-    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_run<ch%d,%s,Q%d,PX%d,TX%d,P%d,NACC%d,%s,bw%d%s%s>", CH, S16 ? "u16" : "u8", Q, PX, TX, P, NACC,
-             p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "", work_suffix(p.work));
+    if (p.fma) resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true, RC, XHL, WS, PH><<<grid, 64 * bw, lds, s>>>(p);
+    else resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false, RC, XHL, WS, PH><<<grid, 64 * bw, lds, s>>>(p);
+    char form[40] = "";
+    if (XHL >= 0) snprintf(form, sizeof form, ",xch%d", XHL);
+    if (WS > 0) snprintf(form + strlen(form), sizeof form - strlen(form), ",ws%d", WS);
+    if (PH > 0) snprintf(form + strlen(form), sizeof form - strlen(form), ",phased%d", p.phase_shift);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_run<ch%d,%s,Q%d,PX%d,TX%d,P%d,NACC%d,%s,bw%d%s%s%s>", CH, S16 ? "u16" : "u8", Q, PX, TX, P, NACC,
+             p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "", form, work_suffix(p.work));
     if (name) *name = g_kernel_name;
     return hipGetLastError();
 }
@@ -617,6 +799,17 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #define PICHA_RUN_LIST_5(X) /* r16g16 */
 #define PICHA_RUN_LIST_6(X) /* r16g16b16 */
 #define PICHA_RUN_LIST_7(X) /* r16g16b16a16 */
+// r04 forms: Z(Q, PX, TX, P, RC, XHL, WS) — XHL >= 0: neighbour exchange with XHL window pixels in front of the lane's own (dword-sized
+// pixels, integer scales: cfg5 = 8K r16g16b16a16 at 4x, 15 taps, windows start 5 pixels before the lane's own eight); WS: phases of the
+// period whose weights stay in SGPRs (cfg3b: one of the two phases of 7.5x).
+#define PICHA_RUNZ_LIST_0(Z) /* rgb */
+#define PICHA_RUNZ_LIST_1(Z) /* rgba */ Z(1, 4, 11, 2, 0, 3, 0) Z(1, 4, 15, 2, 0, 5, 0) Z(1, 3, 8, 2, 0, 2, 0)
+#define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1)
+#define PICHA_RUNZ_LIST_3(Z) /* greya */ Z(2, 15, 30, 2, 1, -1, 1) Z(2, 15, 31, 2, 0, -1, 1)
+#define PICHA_RUNZ_LIST_4(Z) /* r16 */
+#define PICHA_RUNZ_LIST_5(Z) /* r16g16 */
+#define PICHA_RUNZ_LIST_6(Z) /* r16g16b16 */
+#define PICHA_RUNZ_LIST_7(Z) /* r16g16b16a16 */ Z(1, 4, 15, 2, 0, 5, 0) Z(1, 4, 11, 2, 0, 3, 0)
 
 // Ring-kernel instantiations: U(Q, PX, TX, P, RC, K, TYM) — period in outputs / source pixels, x taps, outputs per lane, window
 // offsets inside a period rounded down / up, ring rows, most vertical taps.  Upscales (Q = 2, 4; PX = 1; K = 4): 2x with picha's
@@ -639,26 +832,44 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #define PICHA_CAT2(a, b) a##b
 #define PICHA_CAT(a, b) PICHA_CAT2(a, b)
 #define PICHA_RUN_LIST PICHA_CAT(PICHA_RUN_LIST_, PICHA_RUN_PIXEL)
+#define PICHA_RUNZ_LIST PICHA_CAT(PICHA_RUNZ_LIST_, PICHA_RUN_PIXEL)
 #define PICHA_UP_LIST PICHA_CAT(PICHA_UP_LIST_, PICHA_RUN_PIXEL)
 
-bool PICHA_CAT(run_supported_pixel, PICHA_RUN_PIXEL)(int q, int px, int tx, int per_lane, int nacc, int rc) {
+PICHA_PROBE_HOST(PICHA_CAT(picha_probe_run_p, PICHA_RUN_PIXEL))
+
+bool PICHA_CAT(run_supported_pixel, PICHA_RUN_PIXEL)(int q, int px, int tx, int per_lane, int nacc, int rc, int xhl, int ws) {
     if (nacc != 4 && nacc != 6) return false;
-#define X(Q, PX, TX, P, RC) if (q == Q && px == PX && tx == TX && per_lane == P && rc == RC) return true;
+#define X(Q, PX, TX, P, RC) if (q == Q && px == PX && tx == TX && per_lane == P && rc == RC && xhl < 0 && ws == 0) return true;
     PICHA_RUN_LIST(X)
 #undef X
+#define Z(Q, PX, TX, P, RC, XHL, WS) if (q == Q && px == PX && tx == TX && per_lane == P && rc == RC && xhl == XHL && ws == WS) return true;
+    PICHA_RUNZ_LIST(Z)
+#undef Z
     return false;
 }
 
 hipError_t PICHA_CAT(launch_run_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipStream_t s, const char **name) {
     [[maybe_unused]] constexpr int CH = pixel_channels(PICHA_RUN_PIXEL);
     [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
+    [[maybe_unused]] const int xhl = p.xch ? -p.x_base : -1;
 #define X(Q, PX, TX, P, RC)                                                                               \
-    if (p.period == Q && p.period_px == PX && p.x_taps == TX && p.x_per_lane == P && p.off_ceil == RC) {  \
+    if (p.period == Q && p.period_px == PX && p.x_taps == TX && p.x_per_lane == P && p.off_ceil == RC && xhl < 0 && p.wsgpr == 0) {  \
         if (p.nacc == 4) return launch_run_t<CH, S16, Q, PX, TX, P, 4, RC>(p, s, name);                   \
         if (p.nacc == 6) return launch_run_t<CH, S16, Q, PX, TX, P, 6, RC>(p, s, name);                   \
     }
     PICHA_RUN_LIST(X)
 #undef X
+#define Z(Q, PX, TX, P, RC, XHL, WS)                                                                      \
+    if (p.period == Q && p.period_px == PX && p.x_taps == TX && p.x_per_lane == P && p.off_ceil == RC && xhl == XHL && p.wsgpr == WS) {  \
+        if constexpr (XHL >= 0) {   /* phased stores: the neighbour-exchange shapes */                     \
+            if (p.phase_shift > 0 && p.nacc == 4) return launch_run_t<CH, S16, Q, PX, TX, P, 4, RC, XHL, WS, 1>(p, s, name); \
+            if (p.phase_shift > 0 && p.nacc == 6) return launch_run_t<CH, S16, Q, PX, TX, P, 6, RC, XHL, WS, 1>(p, s, name); \
+        }                                                                                                  \
+        if (p.nacc == 4) return launch_run_t<CH, S16, Q, PX, TX, P, 4, RC, XHL, WS>(p, s, name);          \
+        if (p.nacc == 6) return launch_run_t<CH, S16, Q, PX, TX, P, 6, RC, XHL, WS>(p, s, name);          \
+    }
+    PICHA_RUNZ_LIST(Z)
+#undef Z
     return hipErrorInvalidValue;
 }
 
@@ -681,13 +892,16 @@ hipError_t PICHA_CAT(launch_up_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipSt
 hipError_t PICHA_CAT(launch_edges_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipStream_t s) {
     [[maybe_unused]] constexpr int CH = pixel_channels(PICHA_RUN_PIXEL);
     [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
-    if (!p.stash) return hipSuccess;
+    if (!p.stash && !p.edge_image) return hipSuccess;
     [[maybe_unused]] dim3 grid((p.dst_h + p.edge_rows - 1) / p.edge_rows, 2, p.n_images);
     [[maybe_unused]] const size_t lds = sizeof(float) * kEdgeFloats;
     [[maybe_unused]] const int txe = (p.x_taps + 3) / 4 * 4;
 #define X(Q, PX, TX, P, RC) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
     PICHA_RUN_LIST(X)
 #undef X
+#define Z(Q, PX, TX, P, RC, XHL, WS) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
+    PICHA_RUNZ_LIST(Z)
+#undef Z
 #define U(Q, PX, TX, P, RC, K, TYM) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
     PICHA_UP_LIST(U)
 #undef U

@@ -41,6 +41,7 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
     constexpr int ICLOSE = (TY - 1) / SY, PHCLOSE = (TY - 1) % SY;
     constexpr int YW = (NPEND * SY + 1 + 3) / 4 * 4;  // dwords per step record: NPEND*SY weights, flags in the last dword
     constexpr int TXH = (TX + 1) / 2, TYH = (TY + 1) / 2;
+    PICHA_PROBE_BEGIN
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -219,6 +220,7 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
         if (p.xcd_remap) xcd_contiguous_block(bx, by, bz);
         ibx = int(bx); y0 = int(by) * p.rows_per_chunk; y1 = min(p.dst_h, y0 + p.rows_per_chunk); img = int(bz);
     }, run_item);
+    PICHA_PROBE_END
 }
 
 template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool XCH = false>
@@ -284,6 +286,8 @@ int sym_resident_t(const StreamParams &p) {
 #define PICHA_CAT(a, b) PICHA_CAT2(a, b)
 #define PICHA_SYM_LIST PICHA_CAT(PICHA_SYM_LIST_, PICHA_SYM_PIXEL)
 #define PICHA_SYMX_LIST PICHA_CAT(PICHA_SYMX_LIST_, PICHA_SYM_PIXEL)
+
+PICHA_PROBE_HOST(PICHA_CAT(picha_probe_sym_p, PICHA_SYM_PIXEL))
 
 bool PICHA_CAT(sym_supported_pixel, PICHA_SYM_PIXEL)(int per_lane, int sx, int tx, int sy, int ty, int xch) {
 #define X(P, SX, TX, SY, TY) if (!xch && per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY) return true;

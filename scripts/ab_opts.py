@@ -16,7 +16,7 @@ import picha_amd
 from picha_amd import _native as N
 from picha_amd.device import DeviceBatch, ResizePlan
 
-KNOBS = ('numerics', 'per_lane', 'path', 'row_chunks', 'stream_rot', 'dpp', 'xcd_remap', 'acc', 'sym', 'block_waves', 'sym_sync', 'rows', 'xch', 'acc_p2', 'work', 'work_tail', 'work_tail_div', 'up', 'run', 'run_round')
+KNOBS = ('numerics', 'per_lane', 'path', 'row_chunks', 'stream_rot', 'dpp', 'xcd_remap', 'acc', 'sym', 'block_waves', 'sym_sync', 'rows', 'xch', 'acc_p2', 'work', 'work_tail', 'work_tail_div', 'up', 'run', 'run_round', 'run_xch', 'run_ws', 'run_phase')
 DEFAULTS = {'work_tail': 200, 'work_tail_div': 4}
 
 

@@ -1,0 +1,76 @@
+"""In-kernel shader clock of the resize kernels under their own load (MI355X guide, DVFS item 6): a diagnostic build
+(-DPICHA_CLOCK_PROBE, scripts/r04_build_variant.sh) stamps s_memtime / s_memrealtime at the start and end of every wave;
+clock = sum(d memtime) / sum(d memrealtime) x 100 MHz, read after >= 2 s of back-to-back launches on random pixels.
+
+usage: PICHA_HIP_LIB=picha_amd/variants/libpicha_hip_probe.so python scripts/r04_clock_probe.py
+"""
+import ctypes
+import sys
+import time
+
+sys.path.insert(0, '.')
+import torch
+
+from picha_amd import _native as N
+from picha_amd.device import DeviceBatch, ResizePlan
+
+CASES = [
+    # label, n, pixel, sw, sh, dw, dh, plan options, library options, probe symbol
+    ("cfg2 exact", 256, "rgba", 3840, 2160, 1920, 1080, {}, {}, "picha_probe_sym_p1"),
+    ("cfg2 fma", 256, "rgba", 3840, 2160, 1920, 1080, {}, {"numerics": 1}, "picha_probe_sym_p1"),
+    ("cfg5 exact", 32, "r16g16b16a16", 7680, 4320, 1920, 1080, {"filter": "mitchel"}, {}, "picha_probe_run_p7"),
+    ("cfg5 fma", 32, "r16g16b16a16", 7680, 4320, 1920, 1080, {"filter": "mitchel"}, {"numerics": 1}, "picha_probe_run_p7"),
+    ("cfg3b exact", 256, "grey", 3840, 2160, 512, 512, {"filter": "lanczos"}, {}, "picha_probe_run_p2"),
+    ("cfg3b fma", 256, "grey", 3840, 2160, 512, 512, {"filter": "lanczos"}, {"numerics": 1}, "picha_probe_run_p2"),
+]
+
+
+def main():
+    lib = N.lib()
+    torch.cuda.set_device(0)
+    print("library: %s" % N.SO_PATH)
+    for label, n, pixel, sw, sh, dw, dh, popt, lopt, sym in CASES:
+        try:
+            probe = getattr(lib, sym)
+        except AttributeError:
+            print("%-12s no probe symbol %s in this build" % (label, sym))
+            continue
+        probe.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+        for k, v in lopt.items():
+            N.check(lib.picha_hip_set_option(k.encode(), v))
+        src = DeviceBatch(n, sw, sh, pixel).fill_random(1)
+        dst = DeviceBatch(n, dw, dh, pixel)
+        plan = ResizePlan(src, dst, filter=popt.get("filter"), filter_scale=popt.get("filterScale"))
+        plan.run()
+        torch.cuda.synchronize()
+        name = lib.picha_hip_last_kernel().decode()
+        t0 = time.time()
+        launches = 0
+        while time.time() - t0 < 2.5:   # >= 2 s of back-to-back launches before the stamps that count
+            for _ in range(20):
+                plan.run()
+            torch.cuda.synchronize()
+            launches += 20
+        out = (ctypes.c_ulonglong * 4)()
+        assert probe(out, 1) == 0
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        reps = 100
+        e0.record()
+        for _ in range(reps):
+            plan.run()
+        e1.record()
+        torch.cuda.synchronize()
+        assert probe(out, 0) == 0
+        dt, dr, waves, mx = [int(x) for x in out]
+        ms = e0.elapsed_time(e1) / reps
+        ghz = dt / dr * 0.1 if dr else float("nan")
+        print("%-12s %-86s %.4f ms/launch  in-kernel clock %.3f GHz  (%d waves per launch, mean wave life %.1f us = %.0f ticks, longest %.0f ticks; %d warm-up launches)" % (
+            label, name, ms, ghz, waves // reps, dr / waves * 0.01, dt / waves, mx, launches))
+        for k in lopt:
+            N.check(lib.picha_hip_set_option(k.encode(), 0))
+        del plan, src, dst
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()

@@ -512,3 +512,107 @@ def test_convert_resize_async_batches_and_equals_sync():
         assert np.array_equal(payload(got), payload(picha.convertResizeSync(im, o)))
     with pytest.raises(picha.PichaError, match="expected pixel mode"):
         picha.convertResize(imgs[0], {"width": 4, "height": 4}, lambda e, i: None)
+
+
+# ---- r04: neighbour-exchange form of the run kernel (dword-sized pixels at integer scales) and scalar weights for one phase ----
+RUN_XCH_CASES = [
+    # pixel, (sw, sh), (dw, dh), filter, filterScale, (period_px, taps, window pixels in front of the lane's own)
+    ("r16g16b16a16", (1536, 200), (384, 50), "mitchel", 1.0, (4, 15, 5)),    # cfg5's shape: two waves wide
+    ("r16g16b16a16", (2048, 96), (512, 24), "mitchel", 1.0, (4, 15, 5)),     # 512 outputs: exactly four waves
+    ("r16g16b16a16", (520, 64), (130, 16), "mitchel", 1.0, (4, 15, 5)),      # ragged last wave, one lane beyond the image
+    ("r16g16b16a16", (1024, 80), (256, 20), "cubic", 0.70, (4, 11, 3)),
+    ("rgba", (2048, 120), (512, 30), "cubic", 0.70, (4, 11, 3)),
+    ("rgba", (1000, 64), (250, 16), "mitchel", 1.0, (4, 15, 5)),
+    ("rgba", (1536, 90), (512, 30), "cubic", 0.70, (3, 8, 2)),
+    ("r16g16b16a16", (512, 1400), (128, 350), "mitchel", 1.0, (4, 15, 5)),    # tall: a phased buffer of 8 rows fills many times over
+]
+
+
+@pytest.mark.parametrize("case", RUN_XCH_CASES, ids=lambda c: "%s-%dx%d-%s" % (c[0], c[1][0], c[1][1], c[3]))
+def test_run_kernel_neighbour_exchange_matches_oracle(case):
+    """r04: resize_run<..., xchN>: a lane loads only the pixels it owns, takes the rest of its window from the two neighbouring
+    lanes (DPP wave shifts of raw dwords) and the wave's own halo through LDS; wave-uniform weights; the columns an image edge clips
+    are recomputed by resize_edges_kernel from the IMAGE.  Against the oracle (bit-exact; fma <= 1): chunkings, launch forms,
+    workgroup widths, padded strides, subViews, a device batch; run_xch = 2 gives the kernel it replaces."""
+    from picha_amd.device import DeviceBatch, resize_batch
+    import torch
+    pixel, (sw, sh), (dw, dh), filt, fscale, (px, taps, hl) = case
+    rng = np.random.default_rng(sw + 31 * dh)
+    img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8, 16])))
+    want = oracle_resize(img, dw, dh, filt, fscale)
+    opts = {"width": dw, "height": dh, "filter": filt, "filterScale": fscale}
+    keys = (b"run_xch", b"row_chunks", b"work", b"numerics", b"block_waves", b"run_phase")
+    expect = r"resize_run<ch4,%s,Q1,PX%d,TX%d,P2,NACC\d,(exact|fma),bw\d,xch%d" % ("u16" if pixel.startswith("r16") else "u8", px, taps, hl)
+    try:
+        N.check(N.lib().picha_hip_set_option(b"run_xch", 1))
+        for chunks, work, bw in ((0, 0, 0), (1, 3, 0), (3, 1, 1), (2, 2, 2), (5, 0, 4)):
+            N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
+            N.check(N.lib().picha_hip_set_option(b"work", work))
+            N.check(N.lib().picha_hip_set_option(b"block_waves", bw))
+            got = picha.resizeSync(img, opts)
+            name = N.lib().picha_hip_last_kernel().decode()
+            assert re.match(expect, name) and "+ resize_edges<" in name, name
+            assert max_code_diff(got, want) == 0, (case, chunks, work, bw, name)
+        for k in keys[1:]:
+            N.check(N.lib().picha_hip_set_option(k, 0))
+        # time-phased stores (finished rows wait in registers for a chip-wide clock phase): phases from 0.6 us (every row flushes) to
+        # 10 ms (only full buffers and the end of a chunk flush), one chunk and many
+        for phase, chunks in ((6, 0), (9, 1), (12, 3), (20, 1), (20, 2)):
+            N.check(N.lib().picha_hip_set_option(b"run_phase", phase))
+            N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
+            got = picha.resizeSync(img, opts)
+            name = N.lib().picha_hip_last_kernel().decode()
+            assert ",phased%d" % phase in name, name
+            assert max_code_diff(got, want) == 0, (case, phase, chunks, name)
+        N.check(N.lib().picha_hip_set_option(b"run_phase", 0))
+        N.check(N.lib().picha_hip_set_option(b"row_chunks", 0))
+        sub = None
+        N.check(N.lib().picha_hip_set_option(b"numerics", 1))
+        got = picha.resizeSync(img, opts)
+        assert re.match(expect, N.lib().picha_hip_last_kernel().decode()) and max_code_diff(got, want) <= 1
+        N.check(N.lib().picha_hip_set_option(b"numerics", 0))
+        N.check(N.lib().picha_hip_set_option(b"run_xch", 2))
+        got = picha.resizeSync(img, opts)
+        assert not N.lib().picha_hip_last_kernel().decode().startswith("resize_run<")
+        assert max_code_diff(got, want) == 0
+        N.check(N.lib().picha_hip_set_option(b"run_xch", 1))
+        n = 5
+        src = DeviceBatch(n, sw, sh, pixel).fill_random(11 + sw)
+        out = resize_batch(src, dw, dh, filter=filt, filter_scale=fscale)
+        torch.cuda.synchronize()
+        assert re.match(expect, N.lib().picha_hip_last_kernel().decode())
+        for i in range(n):
+            exp = oracle_resize(src.image_host(i), dw, dh, filt, fscale)
+            assert np.array_equal(out.image_host(i).pixels(), exp.pixels()), (case, i)
+        del sub
+    finally:
+        for k in keys:
+            N.check(N.lib().picha_hip_set_option(k, 0))
+
+
+@pytest.mark.parametrize("pixel,dw", [("grey", 512), ("greya", 256)])
+def test_run_kernel_scalar_phase_weights_match_oracle(pixel, dw):
+    """r04: resize_run<..., ws1>: the second phase of a 7.5x table keeps its weights in SGPRs (31 / 30 registers fewer per lane).
+    Same sums in the same order: bit-exact; run_ws = 2 gives the all-VGPR form, byte-equal."""
+    sw, sh, dh = dw * 15 // 2, 130, 40
+    rng = np.random.default_rng(dw)
+    img = rand_image(rng, sw, sh, pixel)
+    want = oracle_resize(img, dw, dh, "lanczos", 1.0)
+    opts = {"width": dw, "height": dh, "filter": "lanczos"}
+    try:
+        for rnd in (0, 1, 2):
+            N.check(N.lib().picha_hip_set_option(b"run_round", rnd))
+            for ws in (0, 2):
+                N.check(N.lib().picha_hip_set_option(b"run_ws", ws))
+                got = picha.resizeSync(img, opts)
+                name = N.lib().picha_hip_last_kernel().decode()
+                assert name.startswith("resize_run<") and (",ws1" in name) == (ws == 0), name
+                assert max_code_diff(got, want) == 0, (pixel, rnd, ws, name)
+        for k in (b"run_round", b"run_ws"):
+            N.check(N.lib().picha_hip_set_option(k, 0))
+        N.check(N.lib().picha_hip_set_option(b"numerics", 1))
+        got = picha.resizeSync(img, opts)
+        assert ",ws1" in N.lib().picha_hip_last_kernel().decode() and max_code_diff(got, want) <= 1
+    finally:
+        for k in (b"run_round", b"run_ws", b"numerics"):
+            N.check(N.lib().picha_hip_set_option(k, 0))
