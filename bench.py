@@ -258,10 +258,27 @@ def main():
         step_no[0] += 1
         evs[step_no[0]].record()
 
+    local_s = []
     elapsed = timed_region(one_step, args.steps, torch.cuda.synchronize, dist=dist if world > 1 else None,
-                           device=dev if backend == "nccl" else "cpu")
+                           device=dev if backend == "nccl" else "cpu", local_out=local_s)
     launch_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
     avg_launch_ms = sum(launch_ms) / len(launch_ms)
+    sorted_ms = sorted(launch_ms)
+    median_launch_ms = sorted_ms[len(sorted_ms) // 2] if len(sorted_ms) % 2 else 0.5 * (sorted_ms[len(sorted_ms) // 2 - 1] + sorted_ms[len(sorted_ms) // 2])
+    # who took part (r04): a multi-rank line carries the number of ranks that joined the all-reduce, every rank's own time and
+    # the device it ran on, and an RCCL run in which two ranks report the same GPU is refused
+    from picha_amd.shard import duplicate_devices, rank_report
+    props = torch.cuda.get_device_properties(dev)
+    dev_id = "%s/%s" % (getattr(props, "uuid", None) or getattr(props, "pci_bus_id", "?"), torch.cuda.get_device_name(dev))
+    ranks_seen, per_rank_ms, per_rank_dev = rank_report(dist if world > 1 else None, dev if backend == "nccl" else "cpu", local_s[0], dev_id)
+    if world > 1 and backend == "nccl" and duplicate_devices(per_rank_dev):
+        if rank == 0:
+            print("bench.py: ranks share a GPU under the nccl backend: %s" % duplicate_devices(per_rank_dev), file=sys.stderr)
+        dist.destroy_process_group()
+        sys.exit(3)
+    if ranks_seen != world:
+        print("bench.py: %d ranks joined the reduction but WORLD_SIZE is %d" % (ranks_seen, world), file=sys.stderr)
+        sys.exit(3)
 
     # the other numerics flavour, timed the same way on rank 0's batch (reported, not the headline)
     other = None
@@ -284,31 +301,40 @@ def main():
         plan.run()  # leave dst holding the headline flavour's output for the parity sample below
         torch.cuda.synchronize()
 
-    # parity sample: first image of this rank's batch against the oracle (the checker, not the product)
-    parity = None
-    if rank == 0 and not args.no_parity:
+    # parity sample: the first TWO images of every rank's batch against the oracle (the checker, not the product);
+    # rank 0 reports image 0 on its own and the maximum over both images of all ranks
+    parity = parity2 = None
+    if not args.no_parity:
         import numpy as np
 
         import oracle
-        img = src.image_host(0)
-        got = dst.image_host(0)
         filt = opts.get("filter", "cubic")
         fscale = opts.get("filterScale", 1.0 if "filter" in opts else 0.70)
-        if chained and opts.get("order"):   # resize first, then convert
-            mid, _ = oracle.resize(img.data, sw, sh, pixel, dw, dh, filt, fscale)
-            exp, _ = oracle.color_convert(mid, dw, dh, pixel, convert_to)
-        elif chained:
-            mid, _ = oracle.color_convert(img.data, sw, sh, pixel, convert_to)
-            exp, _ = oracle.resize(mid, sw, sh, convert_to, dw, dh, filt, fscale)
-        elif convert_to:
-            exp, _ = oracle.color_convert(img.data, sw, sh, pixel, convert_to)
-        else:
-            exp, _ = oracle.resize(img.data, sw, sh, pixel, dw, dh, filt, fscale)
-        a = got.pixels().astype(np.int64)
-        b = picha_amd.Image(width=dw, height=dh, pixel=dst_pixel, data=exp).pixels().astype(np.int64)
-        parity = int(np.abs(a - b).max())
-        if other is not None:
-            other["parity_max_code_diff_vs_oracle_image0"] = int(np.abs(other_img0.pixels().astype(np.int64) - b).max())
+
+        def expected(img):
+            if chained and opts.get("order"):   # resize first, then convert
+                mid, _ = oracle.resize(img.data, sw, sh, pixel, dw, dh, filt, fscale)
+                e, _ = oracle.color_convert(mid, dw, dh, pixel, convert_to)
+            elif chained:
+                mid, _ = oracle.color_convert(img.data, sw, sh, pixel, convert_to)
+                e, _ = oracle.resize(mid, sw, sh, convert_to, dw, dh, filt, fscale)
+            elif convert_to:
+                e, _ = oracle.color_convert(img.data, sw, sh, pixel, convert_to)
+            else:
+                e, _ = oracle.resize(img.data, sw, sh, pixel, dw, dh, filt, fscale)
+            return picha_amd.Image(width=dw, height=dh, pixel=dst_pixel, data=e).pixels().astype(np.int64)
+
+        diffs = []
+        for i in range(min(2, n)):
+            b = expected(src.image_host(i))
+            diffs.append(int(np.abs(dst.image_host(i).pixels().astype(np.int64) - b).max()))
+            if i == 0 and other is not None:
+                other["parity_max_code_diff_vs_oracle_image0"] = int(np.abs(other_img0.pixels().astype(np.int64) - b).max())
+        parity, parity2 = diffs[0], max(diffs)
+        if world > 1:
+            t = torch.tensor([parity2], dtype=torch.int64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            parity2 = int(t.item())
 
     if rank == 0:
         bpp = N.PIXEL_BYTES[pixel]
@@ -353,11 +379,16 @@ def main():
                 "images_per_gpu": n,
                 "kernel": kernel,
                 "numerics": numerics + (" (fused multiply-add; bar: <= 1 code value from the reference)" if numerics == "fma"
-                                        else " (reference arithmetic; bar: bit-identical)"),
+                                        else " (reference arithmetic; bar: bit-identical; other_numerics carries the fma flavour, which is inside the "
+                                             "north star's <= 1 tolerance and is the line to hold against its HBM-read-roofline sentence)"),
                 "parallelism": "image-sharded x%d" % world,
                 "dst_mpix_per_s": round(n * dw * dh * world * args.steps / elapsed / 1e6, 1),
                 "parity_max_code_diff_vs_oracle_image0": parity,
+                "parity_max_code_diff_vs_oracle_first2_images_all_ranks": parity2,
                 "setup_prewarm_ms": args.prewarm_ms,
+                "ranks_seen": ranks_seen,
+                "per_rank_ms": [round(x, 3) for x in per_rank_ms],
+                "per_rank_device": per_rank_dev,
             },
             "roofline": {
                 "bound": "hbm",
@@ -370,6 +401,10 @@ def main():
                 "kernel": kernel,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(avg_launch_ms, 4),
+                "median_launch_ms": round(median_launch_ms, 4),
+                "min_launch_ms": round(sorted_ms[0], 4),
+                "max_launch_ms": round(sorted_ms[-1], 4),
+                "median_frac": round(alg_bytes / (median_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "read_only_frac": round(read_b / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             },
         }

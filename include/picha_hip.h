@@ -212,6 +212,22 @@ int picha_hip_color_convert(const picha_image *src, const picha_image *dst,
 /* n independent images in one call (one H2D / kernel / D2H pipeline); same semantics per image. */
 int picha_hip_resize_batch(int n, const picha_image *src, const picha_image *dst, int filter,
                            float filter_scale);
+/*
+ * Per-call options (r04).  The reference's options are per call (getResizeOptions, src/resize.cc:173-198); the one knob of this
+ * library that changes RESULTS — the numerics flavour — can be chosen per call too, so that two callers in one process (one Node
+ * process serving two pipelines) do not have to agree on it.  `size` = sizeof(picha_call_opts) (forward compatibility);
+ * numerics: -1 = the process-wide "numerics" option, 0 = reference arithmetic (bit-identical), 1 = fused multiply-add flavour
+ * (at most one code value from the reference).  opts == NULL behaves like the plain entry point.  The asynchronous entry
+ * points take the process-wide option at enqueue time.
+ */
+typedef struct picha_call_opts {
+    int32_t size;
+    int32_t numerics;
+} picha_call_opts;
+int picha_hip_resize_ex(const picha_image *src, const picha_image *dst, int filter, float filter_scale,
+                        const picha_call_opts *opts);
+int picha_hip_resize_batch_ex(int n, const picha_image *src, const picha_image *dst, int filter,
+                              float filter_scale, const picha_call_opts *opts);
 int picha_hip_color_convert_batch(int n, const picha_image *src, const picha_image *dst,
                                   float r_factor, float g_factor, float b_factor);
 
@@ -250,6 +266,9 @@ int picha_hip_resize_device(int n, const picha_image *src, const picha_image *ds
                             float filter_scale, void *stream);
 int picha_hip_color_convert_device(int n, const picha_image *src, const picha_image *dst,
                                    float r_factor, float g_factor, float b_factor, void *stream);
+/* picha_hip_resize_device with per-call options (see picha_call_opts above). */
+int picha_hip_resize_device_ex(int n, const picha_image *src, const picha_image *dst, int filter,
+                               float filter_scale, const picha_call_opts *opts, void *stream);
 
 /* ---- next to the path: colorConvert and resize chained on the device -----------
  * What a picha user writes as  resize(colorConvert(image, {pixel}), {width, height})  — or the other way

@@ -38,6 +38,14 @@ class CImage(ctypes.Structure):
 
 
 # every symbol include/picha_hip.h declares: (name, restype, argtypes)
+class CCallOpts(ctypes.Structure):
+    """picha_call_opts (include/picha_hip.h): per-call options; numerics -1 = process default, 0 exact, 1 fma."""
+    _fields_ = [("size", ctypes.c_int32), ("numerics", ctypes.c_int32)]
+
+    def __init__(self, numerics=-1):
+        super().__init__(ctypes.sizeof(CCallOpts), {"exact": 0, "fma": 1}.get(numerics, numerics))
+
+
 _P = ctypes.POINTER(CImage)
 _i, _f, _d, _vp, _sz = ctypes.c_int, ctypes.c_float, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
 SYMBOLS = [
@@ -61,6 +69,8 @@ SYMBOLS = [
     ("picha_hip_resize", _i, [_P, _P, _i, _f]),
     ("picha_hip_color_convert", _i, [_P, _P, _f, _f, _f]),
     ("picha_hip_resize_batch", _i, [_i, _P, _P, _i, _f]),
+    ("picha_hip_resize_ex", _i, [_P, _P, _i, _f, _vp]),
+    ("picha_hip_resize_batch_ex", _i, [_i, _P, _P, _i, _f, _vp]),
     ("picha_hip_color_convert_batch", _i, [_i, _P, _P, _f, _f, _f]),
     ("picha_hip_resize_async", _i, [_P, _P, _i, _f, _vp, _vp]),
     ("picha_hip_color_convert_async", _i, [_P, _P, _f, _f, _f, _vp, _vp]),
@@ -69,6 +79,7 @@ SYMBOLS = [
     ("picha_hip_async_dispatcher_stats", _i, [_i, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),
     ("picha_hip_resize_device", _i, [_i, _P, _P, _i, _f, _vp]),
     ("picha_hip_color_convert_device", _i, [_i, _P, _P, _f, _f, _f, _vp]),
+    ("picha_hip_resize_device_ex", _i, [_i, _P, _P, _i, _f, _vp, _vp]),
     ("picha_hip_convert_resize_device", _i, [_i, _P, _P, _i, _f, _f, _f, _i, _f, _vp]),
     ("picha_hip_convert_resize", _i, [_P, _P, _i, _f, _f, _f, _i, _f]),
     ("picha_hip_convert_resize_batch", _i, [_i, _P, _P, _i, _f, _f, _f, _i, _f]),

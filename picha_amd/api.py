@@ -161,15 +161,21 @@ def _is_object(o):
     return o is not None and not isinstance(o, (int, float, str, bytes, bool))
 
 
-def _run_resize(src, dst, ftag, fscale):
+def _run_resize(src, dst, ftag, fscale, numerics=None):
     cdst = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index(dst.pixel))
-    N.check(N.lib().picha_hip_resize(ctypes.byref(src[0]), ctypes.byref(cdst), ftag, fscale))
+    if numerics is None:
+        N.check(N.lib().picha_hip_resize(ctypes.byref(src[0]), ctypes.byref(cdst), ftag, fscale))
+    else:   # per-call numerics flavour (picha_call_opts): "exact" / "fma", this call only
+        co = N.CCallOpts(numerics)
+        N.check(N.lib().picha_hip_resize_ex(ctypes.byref(src[0]), ctypes.byref(cdst), ftag, fscale, ctypes.byref(co)))
     return dst
 
 
-def resizeSync(image, opts):
+def resizeSync(image, opts, numerics=None):
+    """picha.resizeSync.  `numerics` ("exact" / "fma") is this library's per-call extension (include/picha_hip.h, picha_call_opts);
+    None = the process-wide option."""
     src, dst, ftag, fscale = _prepare_resize(image, opts, "expected: resizeSync(image, opts)")
-    return _run_resize(src, dst, ftag, fscale)
+    return _run_resize(src, dst, ftag, fscale, numerics)
 
 
 def resize(image, opts, cb):

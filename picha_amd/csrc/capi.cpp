@@ -63,6 +63,8 @@ long g_opt_path = 0;        // 0 auto, 1 two-pass, 2 fused (error if unsupported
 long g_opt_row_chunks = 0;  // 0 auto
 // 0 reference arithmetic (bit-exact, the default), 1 fused-multiply-add flavour (<= 1 code value).
 // PICHA_HIP_NUMERICS=fma|exact in the environment sets the initial value.
+// per-call override of the numerics flavour (picha_hip_*_ex): -1 = none.  Thread-local: the planner runs on the calling thread.
+thread_local int tl_numerics = -1;
 long g_opt_numerics = [] {
     const char *e = getenv("PICHA_HIP_NUMERICS");
     return (e && strcmp(e, "fma") == 0) ? 1L : 0L;
@@ -214,10 +216,30 @@ struct DeviceCtx {
     TempBuf results;     // picha_hip_image_compare_device: per-image sums (device + pinned mirror)
     // work-item lists (kernels.h, WorkList) per (images, output rows, strip blocks, long chunk, short chunk, tail share), and
     // one set of queue counters per stream (launches on a stream are ordered, so they can share it); both under `mu`
-    struct ItemList { void *blob = nullptr; const int4 *items = nullptr; int per_xcd = 0; };
-    std::map<std::tuple<int, int, int, int, int, int>, ItemList> item_lists;
-    std::map<hipStream_t, unsigned *> queues;
+    // (r04) both caches hand out shared ownership: an entry evicted while another host thread is between lookup and
+    // launch stays alive until that thread lets go of it, and its hipFree — which waits for the kernels already enqueued — runs
+    // outside `mu`, from whichever thread drops the last reference.  Eviction takes the least recently used entry, one at a time.
+    struct ItemList {
+        void *blob = nullptr; const int4 *items = nullptr; int per_xcd = 0;
+        unsigned long long used = 0;
+        ItemList() = default;
+        ItemList(const ItemList &) = delete;
+        ItemList &operator=(const ItemList &) = delete;
+        ~ItemList() { if (blob) (void)hipFree(blob); }
+    };
+    struct Queue {
+        unsigned *counters = nullptr;
+        unsigned long long used = 0;
+        Queue() = default;
+        Queue(const Queue &) = delete;
+        Queue &operator=(const Queue &) = delete;
+        ~Queue() { if (counters) (void)hipFree(counters); }
+    };
+    std::map<std::tuple<int, int, int, int, int, int>, std::shared_ptr<ItemList>> item_lists;
+    std::map<hipStream_t, std::shared_ptr<Queue>> queues;
+    unsigned long long use_tick = 0;
 };
+constexpr size_t kMaxItemLists = 64, kMaxQueues = 256;
 
 std::mutex g_ctx_mu;
 std::map<int, std::unique_ptr<DeviceCtx>> g_ctx;
@@ -782,7 +804,7 @@ bool acc_xch_preferred(int pixel, int step, int taps, int per_lane, int fma) {
 int sym_preferred_per_lane(int pixel, int step, int taps, int fma) {
     struct E { int8_t step, taps, exact, fma; };
     static const E rgb[] = {{2, 5, 0, 4}, {3, 8, 4, 0}, {4, 11, 0, 4}, {4, 15, 0, 4}, {0, 0, 0, 0}};
-    static const E rgba[] = {{2, 5, 3, 2}, {2, 7, 0, 2}, {3, 8, 2, 2}, {4, 11, 0, 2} /* exact: the two-output accumulator kernel is ahead */, {4, 15, 0, 2}, {0, 0, 0, 0}};
+    static const E rgba[] = {{2, 5, 3, 3} /* fma: 3 outputs per lane 1.883 -> 1.858 ms and less fabric traffic (r04, profiles/r04_ab_cfg2_per_lane.txt) */, {2, 7, 0, 2}, {3, 8, 2, 2}, {4, 11, 0, 2} /* exact: the two-output accumulator kernel is ahead */, {4, 15, 0, 2}, {0, 0, 0, 0}};
     static const E grey[] = {{2, 5, 0, 4}, {2, 7, 0, 4}, {0, 0, 0, 0}};
     static const E greya[] = {{2, 3, 0, 2}, {2, 5, 0, 4}, {2, 7, 0, 4}, {3, 8, 2, 2}, {3, 12, 2, 0}, {0, 0, 0, 0}};
     static const E r16[] = {{2, 3, 4, 2}, {2, 5, 4, 4}, {2, 7, 4, 4}, {3, 8, 2, 2}, {3, 12, 2, 2}, {4, 11, 2, 2}, {0, 0, 0, 0}};
@@ -799,14 +821,18 @@ int sym_preferred_per_lane(int pixel, int step, int taps, int fma) {
 // contiguous eighths; inside an eighth the last `tail_pm` per mille of the units are cut into short chunks, and every
 // (image, rows) piece becomes `nsb` consecutive items, one per column-strip block.  Sub-lists are padded to equal length
 // with empty items.  Built once per key, then a lookup.
-int get_items(DeviceCtx *ctx, int n, int dst_h, int nsb, int rows_long, int rows_short, int tail_pm, const DeviceCtx::ItemList **out) {
-    std::lock_guard<std::mutex> lk(ctx->mu);
+int get_items(DeviceCtx *ctx, int n, int dst_h, int nsb, int rows_long, int rows_short, int tail_pm, std::shared_ptr<const DeviceCtx::ItemList> *out) {
+    std::shared_ptr<DeviceCtx::ItemList> evicted;   // released after `mu`: its hipFree synchronises the device
+    std::unique_lock<std::mutex> lk(ctx->mu);
     auto key = std::make_tuple(n, dst_h, nsb, rows_long, rows_short, tail_pm);
     auto it = ctx->item_lists.find(key);
-    if (it != ctx->item_lists.end()) { *out = &it->second; return PICHA_OK; }
-    if (ctx->item_lists.size() >= 64) {  // bounded: drop everything (hipFree waits for the kernels still reading them)
-        for (auto &kv : ctx->item_lists) (void)hipFree(kv.second.blob);
-        ctx->item_lists.clear();
+    if (it != ctx->item_lists.end()) { it->second->used = ++ctx->use_tick; *out = it->second; return PICHA_OK; }
+    if (ctx->item_lists.size() >= kMaxItemLists) {
+        auto lru = ctx->item_lists.begin();
+        for (auto j = ctx->item_lists.begin(); j != ctx->item_lists.end(); ++j)
+            if (j->second->used < lru->second->used) lru = j;
+        evicted = std::move(lru->second);
+        ctx->item_lists.erase(lru);
     }
     struct Unit { int img, y0, y1; };
     std::vector<Unit> units;
@@ -833,34 +859,44 @@ int get_items(DeviceCtx *ctx, int n, int dst_h, int nsb, int rows_long, int rows
     for (auto &l : lists) per = std::max(per, l.size());
     std::vector<int4> flat(per * 8, make_int4(0, 0, 0, 0));
     for (int x = 0; x < 8; ++x) std::copy(lists[x].begin(), lists[x].end(), flat.begin() + (long)(per * x));
-    DeviceCtx::ItemList il;
-    HIP_TRY(hipMalloc(&il.blob, flat.size() * sizeof(int4)));
-    HIP_TRY(hipMemcpy(il.blob, flat.data(), flat.size() * sizeof(int4), hipMemcpyHostToDevice));
-    il.items = static_cast<const int4 *>(il.blob);
-    il.per_xcd = (int)per;
-    auto ins = ctx->item_lists.emplace(key, il);
-    *out = &ins.first->second;
+    auto il = std::make_shared<DeviceCtx::ItemList>();
+    HIP_TRY(hipMalloc(&il->blob, flat.size() * sizeof(int4)));
+    HIP_TRY(hipMemcpy(il->blob, flat.data(), flat.size() * sizeof(int4), hipMemcpyHostToDevice));
+    il->items = static_cast<const int4 *>(il->blob);
+    il->per_xcd = (int)per;
+    il->used = ++ctx->use_tick;
+    ctx->item_lists.emplace(key, il);
+    *out = il;
+    lk.unlock();
+    evicted.reset();
     return PICHA_OK;
 }
 
-// the stream's queue counters, zeroed in stream order for the launch that follows
-int get_queue(DeviceCtx *ctx, hipStream_t s, unsigned **out) {
-    unsigned *q = nullptr;
+// the stream's queue counters, zeroed in stream order for the launch that follows; *hold keeps them alive for the caller's launch
+int get_queue(DeviceCtx *ctx, hipStream_t s, unsigned **out, std::shared_ptr<const DeviceCtx::Queue> *hold) {
+    std::shared_ptr<DeviceCtx::Queue> q, evicted;
     {
         std::lock_guard<std::mutex> lk(ctx->mu);
         auto it = ctx->queues.find(s);
         if (it != ctx->queues.end()) q = it->second;
         else {
-            if (ctx->queues.size() >= 256) {
-                for (auto &kv : ctx->queues) (void)hipFree(kv.second);
-                ctx->queues.clear();
+            if (ctx->queues.size() >= kMaxQueues) {
+                auto lru = ctx->queues.begin();
+                for (auto j = ctx->queues.begin(); j != ctx->queues.end(); ++j)
+                    if (j->second->used < lru->second->used) lru = j;
+                evicted = std::move(lru->second);
+                ctx->queues.erase(lru);
             }
-            HIP_TRY(hipMalloc((void **)&q, 64));
+            q = std::make_shared<DeviceCtx::Queue>();
+            HIP_TRY(hipMalloc((void **)&q->counters, 64));
             ctx->queues[s] = q;
         }
+        q->used = ++ctx->use_tick;
     }
-    HIP_TRY(hipMemsetAsync(q, 0, 64, s));
-    *out = q;
+    evicted.reset();   // outside `mu`
+    HIP_TRY(hipMemsetAsync(q->counters, 0, 64, s));
+    *out = q->counters;
+    *hold = q;
     return PICHA_OK;
 }
 
@@ -932,9 +968,12 @@ long g_opt_run_phase = 0;  // time-phased stores of the neighbour-exchange run k
 
 // where the neighbour-exchange run kernel is the default: cfg5's shape (r16g16b16a16 at 4x, 15 taps) — measured r04 against the
 // r03 accumulator form (lane-resident weights, 157 VGPRs, 3 waves per SIMD): profiles/r04_ab_run_xch.txt
+// (2.03 -> 1.87-1.93 ms, fma 1.94 -> 1.75-1.79), the same format with picha's default 11 taps (64 x 4K -> 960x540: 1.05 -> 0.92 ms, fma
+// 1.05 -> 0.90), and rgba at 4x in the fma flavour (11 taps 1.01 -> 0.93, 15 taps 1.10 -> 1.02; the reference arithmetic is 6-20 % slower
+// there, and rgba at 3x loses in both): profiles/r04_survey_run_xch.txt
 bool run_xch_preferred(int pixel, int period_px, int taps, int per_lane, int fma) {
-    (void)fma;
-    return pixel == PICHA_R16G16B16A16 && period_px == 4 && taps == 15 && per_lane == 2;
+    if (per_lane != 2 || period_px != 4 || (taps != 11 && taps != 15)) return false;
+    return pixel == PICHA_R16G16B16A16 || (pixel == PICHA_RGBA && fma);
 }
 
 // Run kernel for one equal-geometry group: downscales whose x scale is a ratio of small integers with a long window.
@@ -947,7 +986,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
         opt_run_xch = g_opt_run_xch; opt_run_ws = g_opt_run_ws; opt_run_phase = g_opt_run_phase;
-        opt_run = g_opt_run; opt_run_round = g_opt_run_round; opt_numerics = g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
+        if (g_opt_xch != 0 && opt_run_xch == 0) opt_run_xch = 2;   // "xch" = 1 / 2 asks for / rules out the exchange forms of the symmetric-table and accumulator kernels: not this one
+        opt_run = g_opt_run; opt_run_round = g_opt_run_round; opt_numerics = tl_numerics >= 0 ? tl_numerics : g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
         opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
         opt_bw = g_opt_block_waves;
     }
@@ -987,6 +1027,25 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // The register ring reproduces the reference's ring whenever it has the reference's length, or the table has no aliasing and
     // no output row needs more rows than the ring holds (taps.cpp: eff[] = the last row <= need[] in the tap's residue class).
     int ring_rows = 0;
+    {   //  no instantiation for this format / period at all (rgb, most 16-bit formats): leave before any device table is
+        // built — get_yrows below allocates and uploads per axis
+        int xb0 = 0;
+        bool any = false;
+        for (int c = 0; c < 2 && !any; ++c) {
+            const int t0 = run_table_taps(ax->host, period, period_px, c, &xb0);
+            for (int tx = t0; t0 > 0 && tx <= t0 + 3 && !any; ++tx)
+                for (int pl : {2, 4, 8}) {
+                    if (up) { for (int k : {4}) any = any || up_kernel_supported(pixel, period, period_px, tx, pl, c, k, ay->host.taps); }
+                    else {
+                        for (int na : {4, 6})
+                            any = any || run_kernel_supported(pixel, period, period_px, tx, pl, na, c) || run_kernel_supported(pixel, period, period_px, tx, pl, na, c, -1, 1) ||
+                                  (c == 0 && xb0 <= 0 && run_kernel_supported(pixel, period, period_px, tx, pl, na, 0, -xb0, 0));
+                        for (int k : {8, 16}) any = any || up_kernel_supported(pixel, period, period_px, tx, pl, c, k, ay->host.taps);
+                    }
+                }
+        }
+        if (!any) return PICHA_OK;
+    }
     if (!up) {
         for (int na : {4, 6}) {
             const DeviceAxis::YRows *cand = nullptr;
@@ -1040,7 +1099,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         for (int tx = tx_of[c]; tx <= tx_of[c] + 3 && !per_lane; ++tx)
             for (int pl0 : (up || (period == 2 && period_px == 3) ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
                 const int pl = opt_per_lane > 0 ? (int)opt_per_lane : pl0;   // "per_lane" names the run length outright
-                if (pl % period || !(ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c))) continue;
+                if (pl % period || !(ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : (run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c) || (opt_run_ws != 2 && run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c, -1, 1))))) continue;
                 per_lane = pl; ktaps = tx; ceil_off = c;
                 break;
             }
@@ -1187,7 +1246,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // launch form: the plain grid (measured r03 on cfg3b: item list +3 %, persistent +30 %; the edge kernel follows either way)
     const int work_mode = !ring_mode && (opt_work == 1 || opt_work == 2) ? (int)opt_work : 0;
     if (work_mode) {
-        const DeviceCtx::ItemList *il = nullptr;
+        std::shared_ptr<const DeviceCtx::ItemList> il;
+            std::shared_ptr<const DeviceCtx::Queue> qhold;
         rc = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(16, p.rows_per_chunk / (int)opt_work_tail_div), (int)opt_work_tail, &il);
         if (rc) { (void)release_temps(); return rc; }
         p.n_images = n;
@@ -1195,9 +1255,9 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         if (work_mode == 2) {
             const int resident = run_kernel_resident_blocks(pixel, p);
             if (resident > 0 && (long long)il->per_xcd * 8 > 2LL * resident) {
-                rc = get_queue(ctx, s, &p.work.queue);
+                rc = get_queue(ctx, s, &p.work.queue, &qhold);
                 if (rc) { (void)release_temps(); return rc; }
-                p.n_chunks = resident / 8 * 8;
+                p.n_chunks = std::max(8, resident / 8 * 8);
             }
         }
         hipError_t e = launch_resize_run_kernel(pixel, p, s, &g_last_kernel);
@@ -1249,7 +1309,7 @@ int rows_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, i
     long opt_rows, opt_numerics, opt_chunks, opt_per_lane;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
-        opt_rows = g_opt_rows; opt_numerics = g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
+        opt_rows = g_opt_rows; opt_numerics = tl_numerics >= 0 ? tl_numerics : g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
     }
     if (variant < 0 || opt_rows == 2) return PICHA_OK;
     if (d0.width >= s0.width || d0.height >= s0.height) return PICHA_OK;  // downscales only
@@ -1426,7 +1486,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
         opt_xch = g_opt_xch;
         opt_sym = g_opt_sym; opt_bw = g_opt_block_waves; opt_sym_sync = g_opt_sym_sync; opt_acc_p2 = g_opt_acc_p2; opt_long_block = g_opt_long_block;
-        opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = g_opt_numerics; opt_per_lane = g_opt_per_lane;
+        opt_path = g_opt_path; opt_chunks = g_opt_row_chunks; opt_numerics = tl_numerics >= 0 ? tl_numerics : g_opt_numerics; opt_per_lane = g_opt_per_lane;
         opt_rot = g_opt_stream_rot;
         opt_dpp = g_opt_dpp;
         opt_xcd = g_opt_xcd_remap;
@@ -1598,7 +1658,8 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             const int work_mode = !sym || p.sync_steps ? 0 : opt_work == 3 ? 0 : opt_work > 0 ? (int)opt_work : work_default(n, col_waves, p.n_chunks, false, false);
             if (work_mode) {
                 const int nsb = (int)((cx->groups + 64 * bw - 1) / (64 * bw));
-                const DeviceCtx::ItemList *il = nullptr;
+                std::shared_ptr<const DeviceCtx::ItemList> il;
+            std::shared_ptr<const DeviceCtx::Queue> qhold;
                 // short chunks at the end of every sub-list only where a chunk's halo (TY - SY source rows re-filtered) is short:
                 // cfg2 (3 rows) gains 1 % from a 20-25 % tail, cfg5 (11 rows) loses 4 % to it (profiles/r03_ab_work_items.txt)
                 const int tail_pm = (ay->host.taps - sy) <= 2 * sy ? (int)opt_work_tail : 0;
@@ -1609,9 +1670,9 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 if (work_mode == 2) {
                     const int resident = sym_kernel_resident_blocks(pixel, p);
                     if (resident > 0 && (long long)il->per_xcd * 8 > 2LL * resident) {
-                        rc2 = get_queue(ctx, s, &p.work.queue);
+                        rc2 = get_queue(ctx, s, &p.work.queue, &qhold);
                         if (rc2) return rc2;
-                        p.n_chunks = resident / 8 * 8;
+                        p.n_chunks = std::max(8, resident / 8 * 8);
                     }
                 }
                 const hipError_t e = launch_resize_sym_kernel(pixel, p, s, &g_last_kernel);
@@ -1911,7 +1972,8 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         const int work_mode = !use_acc || ktaps > 36 ? 0 : opt_work == 3 ? 0 : opt_work > 0 ? (int)opt_work : work_default(n, col_waves, p.n_chunks, true, acc_xch);
         if (work_mode) {
             const int nsb = (xt->groups + 255) / 256;
-            const DeviceCtx::ItemList *il = nullptr;
+            std::shared_ptr<const DeviceCtx::ItemList> il;
+            std::shared_ptr<const DeviceCtx::Queue> qhold;
             const double src_per_out = std::max(1.0, (double)s0.height / d0.height);
             const int tail_pm = ring <= 2 * src_per_out ? (int)opt_work_tail : 0;   // as above: only where the halo is short
             rc = get_items(ctx, n, d0.height, nsb, p.rows_per_chunk, std::max(16, p.rows_per_chunk / (int)opt_work_tail_div), tail_pm, &il);
@@ -1920,9 +1982,9 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             if (work_mode == 2) {
                 const int resident = acc_kernel_resident_blocks(pixel, p);
                 if (resident > 0 && (long long)il->per_xcd * 8 > 2LL * resident) {
-                    rc = get_queue(ctx, s, &p.work.queue);
+                    rc = get_queue(ctx, s, &p.work.queue, &qhold);
                     if (rc) return rc;
-                    p.n_chunks = resident / 8 * 8;
+                    p.n_chunks = std::max(8, resident / 8 * 8);
                 }
             }
             const hipError_t e = launch_resize_acc(pixel, p, s, &g_last_kernel);
@@ -2039,7 +2101,7 @@ struct HostLane {
     uint8_t *pinned = nullptr; size_t pinned_cap = 0;
     uint8_t *arena = nullptr;  size_t arena_cap = 0;
     std::chrono::steady_clock::time_point idle_since;
-    size_t held_bytes() const { return pinned_cap; }   // (and as many device bytes)
+    size_t held_bytes() const { return pinned_cap + arena_cap; }   // pinned host staging + device arena
 };
 using LanePool = LanePoolT<HostLane>;
 std::mutex g_lane_mu;
@@ -2607,6 +2669,34 @@ int picha_hip_validate_host_op(int kind, const picha_image *src, const picha_ima
 // ---- host-pointer entry points --------------------------------------------------------------------
 int picha_hip_resize(const picha_image *src, const picha_image *dst, int filter, float filter_scale) {
     return run_host(Op::Resize, 1, src, dst, filter, filter_scale, 0, 0, 0);
+}
+namespace {
+// scope of a per-call numerics override; rc != 0: the options were malformed
+struct CallOpts {
+    int saved, rc = PICHA_OK;
+    explicit CallOpts(const picha_call_opts *o) : saved(tl_numerics) {
+        if (!o) return;
+        if (o->size < (int32_t)sizeof(picha_call_opts) || o->numerics < -1 || o->numerics > 1) { rc = fail(PICHA_ERR_ARGUMENT, "bad picha_call_opts"); return; }
+        if (o->numerics >= 0) tl_numerics = o->numerics;
+    }
+    ~CallOpts() { tl_numerics = saved; }
+};
+}  // namespace
+int picha_hip_resize_ex(const picha_image *src, const picha_image *dst, int filter, float filter_scale, const picha_call_opts *opts) {
+    CallOpts scope(opts);
+    if (scope.rc) return scope.rc;
+    return run_host(Op::Resize, 1, src, dst, filter, filter_scale, 0, 0, 0);
+}
+int picha_hip_resize_batch_ex(int n, const picha_image *src, const picha_image *dst, int filter, float filter_scale, const picha_call_opts *opts) {
+    CallOpts scope(opts);
+    if (scope.rc) return scope.rc;
+    return run_host(Op::Resize, n, src, dst, filter, filter_scale, 0, 0, 0);
+}
+int picha_hip_resize_device_ex(int n, const picha_image *src, const picha_image *dst, int filter, float filter_scale, const picha_call_opts *opts,
+                               void *stream) {
+    CallOpts scope(opts);
+    if (scope.rc) return scope.rc;
+    return picha_hip_resize_device(n, src, dst, filter, filter_scale, stream);
 }
 int picha_hip_color_convert(const picha_image *src, const picha_image *dst, float r, float g, float b) {
     return run_host(Op::Convert, 1, src, dst, 0, 0, r, g, b);

@@ -225,7 +225,11 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(RowsParams p) {
         for (int a = 0; a < NACC; ++a) {
             const int y = rec[NACC + a];
             if (y >= 0) {  // workgroup-uniform
+#ifdef PICHA_ROWS_NOSTORE   // measurement builds only: everything but the output stores (one row per chunk is stored)
+                if (y == y0) {
+#else
                 if (y >= y0 && y < y1) {
+#endif
 #pragma unroll
                     for (int q = 0; q < P; ++q)
                         if (x0 + q < p.dst_w) {

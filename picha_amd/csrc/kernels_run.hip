@@ -28,7 +28,8 @@
 #define PICHA_RUN_XNB 2   // row buffers of the neighbour-exchange form
 #endif
 // measurement builds only (scripts/r04_ablate.sh; results are wrong by construction): 1 = loads and stores without the arithmetic,
-// 2 = arithmetic and stores without the loads in the loop, 3 = no halo exchange (the lane's own pixels stand in for its neighbours')
+// 2 = arithmetic and stores without the loads in the loop, 3 = no halo exchange (the lane's own pixels stand in for its neighbours'),
+// 4 = everything but the output stores (one row per chunk is stored)
 #ifndef PICHA_RUN_ABLATE
 #define PICHA_RUN_ABLATE 0
 #endif
@@ -502,7 +503,12 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
                         ++nbuf;
                     }
                 } else {
-                    if (y >= y0 && y < y1) store_lane_outputs<C, CH, S16, P, FMA>(acc[PICHA_RUN_ABLATE == 1 ? 0 : a], dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
+#if PICHA_RUN_ABLATE == 4   // no output stores (one row per chunk keeps the arithmetic alive)
+                    if (y == y0)
+#else
+                    if (y >= y0 && y < y1)
+#endif
+                        store_lane_outputs<C, CH, S16, P, FMA>(acc[PICHA_RUN_ABLATE == 1 ? 0 : a], dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
                 }
 #pragma unroll
                 for (int o = 0; o < P; ++o)
@@ -802,6 +808,8 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // r04 forms: Z(Q, PX, TX, P, RC, XHL, WS) — XHL >= 0: neighbour exchange with XHL window pixels in front of the lane's own (dword-sized
 // pixels, integer scales: cfg5 = 8K r16g16b16a16 at 4x, 15 taps, windows start 5 pixels before the lane's own eight); WS: phases of the
 // period whose weights stay in SGPRs (cfg3b: one of the two phases of 7.5x).
+// Measured and not kept (profiles/r04_ab_run_ws.txt): both phases scalar (97 VGPRs, one short of a fifth wave per SIMD: +2 % exact, +12 % fma),
+// eight outputs per lane for the 30-tap shape (SGPR spills), two row buffers instead of three (a tie).
 #define PICHA_RUNZ_LIST_0(Z) /* rgb */
 #define PICHA_RUNZ_LIST_1(Z) /* rgba */ Z(1, 4, 11, 2, 0, 3, 0) Z(1, 4, 15, 2, 0, 5, 0) Z(1, 3, 8, 2, 0, 2, 0)
 #define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1)

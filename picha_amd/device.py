@@ -111,7 +111,7 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def resize_batch(src, dst_width=None, dst_height=None, filter=None, filter_scale=None, out=None, opts=None):
+def resize_batch(src, dst_width=None, dst_height=None, filter=None, filter_scale=None, out=None, opts=None, numerics=None):
     """picha.resize over a device-resident batch; same option semantics as resizeSync.
 
     Asynchronous on torch's current stream.  Returns the destination DeviceBatch.
@@ -130,7 +130,12 @@ def resize_batch(src, dst_width=None, dst_height=None, filter=None, filter_scale
             raise N.PichaError("invalid dimensions")
         out = DeviceBatch(src.n, w, h, src.pixel, device=src.tensor.device)
     with torch.cuda.device(src.tensor.device):
-        N.check(N.lib().picha_hip_resize_device(src.n, src.descriptors(), out.descriptors(), ftag, fscale, _stream(src.tensor)))
+        if numerics is None:
+            N.check(N.lib().picha_hip_resize_device(src.n, src.descriptors(), out.descriptors(), ftag, fscale, _stream(src.tensor)))
+        else:   # per-call numerics flavour ("exact" / "fma")
+            import ctypes
+            co = N.CCallOpts(numerics)
+            N.check(N.lib().picha_hip_resize_device_ex(src.n, src.descriptors(), out.descriptors(), ftag, fscale, ctypes.byref(co), _stream(src.tensor)))
     return out
 
 

@@ -19,7 +19,14 @@ for n in 0 1 2 3 4 5 6 7; do
     symobjs="$symobjs build/var_$tag/sym_p$n.o"
   else symobjs="$symobjs build/sym_p$n.o"; fi
 done
+rowsobjs=""
+for n in 0 1 2 3 4 5 6 7 8 9 10 11; do
+  if [[ " $ROWS_VAR " == *" $n "* ]]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize -DPICHA_ROWS_VARIANT=$n $flags -c kernels_rows.hip -o build/var_$tag/rows_v$n.o &
+    rowsobjs="$rowsobjs build/var_$tag/rows_v$n.o"
+  else rowsobjs="$rowsobjs build/rows_v$n.o"; fi
+done
 wait
-rest="$(ls build/*.o | grep -v "build/run_p" | grep -v "build/sym_p") $symobjs"
+rest="$(ls build/*.o | grep -v "build/run_p" | grep -v "build/sym_p" | grep -v "build/rows_v") $symobjs $rowsobjs"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libpicha_hip_$tag.so $rest $objs
 ls -la ../variants/libpicha_hip_$tag.so

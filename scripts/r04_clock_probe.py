@@ -51,8 +51,9 @@ def main():
                 plan.run()
             torch.cuda.synchronize()
             launches += 20
-        out = (ctypes.c_ulonglong * 4)()
-        assert probe(out, 1) == 0
+        SLOTS = 1 << 17
+        out = (ctypes.c_ulonglong * (2 * SLOTS))()
+        assert probe(out, 1) == SLOTS
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 100
         e0.record()
@@ -60,12 +61,15 @@ def main():
             plan.run()
         e1.record()
         torch.cuda.synchronize()
-        assert probe(out, 0) == 0
-        dt, dr, waves, mx = [int(x) for x in out]
+        assert probe(out, 0) == SLOTS
+        import numpy as np
+        a = np.frombuffer(out, dtype=np.uint64).reshape(SLOTS, 2).astype(np.float64)
+        a = a[a[:, 1] > 0]
+        ghz = a[:, 0] / a[:, 1] * 0.1
         ms = e0.elapsed_time(e1) / reps
-        ghz = dt / dr * 0.1 if dr else float("nan")
-        print("%-12s %-86s %.4f ms/launch  in-kernel clock %.3f GHz  (%d waves per launch, mean wave life %.1f us = %.0f ticks, longest %.0f ticks; %d warm-up launches)" % (
-            label, name, ms, ghz, waves // reps, dr / waves * 0.01, dt / waves, mx, launches))
+        print("%-12s %-86s %.4f ms/launch  in-kernel clock: median %.3f GHz (p10 %.3f, p90 %.3f; by sums %.3f) over the last launch's %d wave slots, "
+              "median wave life %.1f us; %d warm-up launches" % (label, name, ms, float(np.median(ghz)), float(np.percentile(ghz, 10)),
+              float(np.percentile(ghz, 90)), float(a[:, 0].sum() / a[:, 1].sum() * 0.1), len(a), float(np.median(a[:, 1])) * 0.01, launches))
         for k in lopt:
             N.check(lib.picha_hip_set_option(k.encode(), 0))
         del plan, src, dst

@@ -56,6 +56,28 @@ int main() {
         pool.give(l);
         CHECK(pool.idle_count() == before + 1);                     // give() frees nothing
     }
+    {   // (r04) a burst of 40 concurrent callers long ago must not pin 40 lanes for ever: once the peak windows have rolled over (here:
+        // windows of zero seconds) the count rule retires every idle lane beyond kMinIdle that has idled long enough — under an
+        // unlimited byte budget
+        std::vector<DummyLane *> held;
+        for (int i = 0; i < 40; ++i) {
+            std::vector<DummyLane *> surplus;
+            DummyLane *l = pool.take(&surplus);
+            for (DummyLane *d : surplus) { delete d; ++destroyed; }
+            if (!l) { l = new DummyLane; ++created; }
+            held.push_back(l);
+        }
+        for (DummyLane *l : held) pool.give(l);
+        CHECK(pool.idle_count() >= 40);
+        for (int k = 0; k < 3; ++k) {   // three takes: the 40-wide window becomes the previous one, then drops out
+            std::vector<DummyLane *> surplus;
+            DummyLane *l = pool.take(&surplus, /*idle_seconds=*/0, /*budget=*/(size_t)-1, /*peak_window_seconds=*/0);
+            for (DummyLane *d : surplus) { delete d; ++destroyed; }
+            CHECK(l != nullptr);
+            pool.give(l);
+        }
+        CHECK(pool.idle_count() <= Pool::kMinIdle);
+    }
     // tidy up for the leak checker
     for (;;) {
         std::vector<DummyLane *> surplus;

@@ -32,6 +32,18 @@ def test_library_exports_every_declared_symbol():
     assert bound == names
 
 
+def test_library_exports_nothing_but_the_header(tmp_path):
+    """r04: the exported surface IS the C header (linker version script picha_amd/csrc/exports.map, generated from it by
+    scripts/gen_exports.py): no C++ launchers, no kernel stubs, no helper that happens to be extern "C"."""
+    import subprocess
+    names = declared_functions()
+    out = subprocess.run(["nm", "-D", "--defined-only", N.SO_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted(line.split()[-1] for line in out.splitlines() if line.strip())
+    assert exported == names, sorted(set(exported) ^ set(names))
+    listed = sorted(re.findall(r"^\s+(picha_[a-z0-9_]+);", open(os.path.join(ROOT, "picha_amd", "csrc", "exports.map")).read(), flags=re.M))
+    assert listed == names
+
+
 def test_cheap_calls_work_without_a_gpu():
     L = N.lib()
     assert [L.picha_pixel_bytes(i) for i in range(8)] == [3, 4, 1, 2, 2, 4, 6, 8]
@@ -122,8 +134,8 @@ def test_reference_arithmetic_kernels_have_no_fused_multiply_add(device_disassem
             re.search(r"resize_stream_dpp_kernelI.*ELb([01])EEEvNS_", name) or \
             re.search(r"resize_sym_kernelI.*ELb([01])ELb[01]EEEvNS_", name) or \
             re.search(r"resize_rows_kernelI.*ELb([01])EEEvNS_", name) or \
-            re.search(r"resize_run_kernelI.*ELb([01])ELi[01]EEEvNS_", name) or \
-            re.search(r"resize_ring_kernelI.*ELb([01])ELi[01]EEEvNS_", name)  # <..., FMA, RC>; resize_edges_kernel is reference arithmetic only
+            re.search(r"resize_run_kernelI.*ELb([01])ELi[01]ELin?\d+ELi\d+ELi[01]EEEvNS_", name) or \
+            re.search(r"resize_ring_kernelI.*ELb([01])ELi[01]EEEvNS_", name)  # run: <..., FMA, RC, XHL, WS, PH>, ring: <..., FMA, RC>; resize_edges_kernel is reference arithmetic only
         if m and m.group(1) == "1":
             fma_flavour += 1
             assert body["fused"], "fma flavour without fma? " + name

@@ -25,18 +25,21 @@ def _worker(rank, world, port, n_images, out_q):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-    from picha_amd.shard import shard_range, timed_region
+    from picha_amd.shard import duplicate_devices, rank_report, shard_range, timed_region
     lo, hi = shard_range(n_images, rank, world)
     # every rank "processes" its own images (stand-in work: mark them), no exchange of pixel data
     owned = torch.zeros(n_images, dtype=torch.int64)
     owned[lo:hi] = rank + 1
     import time
-    elapsed = timed_region(lambda: time.sleep(0.01 * (rank + 1)), steps=3, sync=lambda: None, dist=dist)
+    local = []
+    elapsed = timed_region(lambda: time.sleep(0.01 * (rank + 1)), steps=3, sync=lambda: None, dist=dist, local_out=local)
+    # the self-check fields of bench.py's multi-rank line (r04): ranks that joined, each rank's own time, each rank's device
+    seen, per_rank_ms, per_rank_dev = rank_report(dist, "cpu", local[0], "fake-gpu-%d" % (rank if n_images != 7 else 0))
     # verification only (not part of the data path): ownership must partition the batch
     dist.all_reduce(owned, op=dist.ReduceOp.SUM)
     total = torch.tensor([hi - lo], dtype=torch.int64)
     dist.all_reduce(total, op=dist.ReduceOp.SUM)
-    out_q.put((rank, lo, hi, elapsed, owned.tolist(), int(total.item())))
+    out_q.put((rank, lo, hi, elapsed, owned.tolist(), int(total.item()), seen, per_rank_ms, per_rank_dev, duplicate_devices(per_rank_dev)))
     dist.destroy_process_group()
 
 
@@ -53,9 +56,53 @@ def test_two_rank_sharding_and_timing(n_images):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, lo0, hi0, e0, owned0, tot0), (r1, lo1, hi1, e1, owned1, tot1) = results
+    (r0, lo0, hi0, e0, owned0, tot0, seen0, ms0, dev0, dup0), (r1, lo1, hi1, e1, owned1, tot1, seen1, ms1, dev1, dup1) = results
+    assert seen0 == seen1 == world and ms0 == ms1 and dev0 == dev1               # every rank holds the same report
+    assert ms0[1] > ms0[0] >= 3 * 10 * 0.9 and ms0[1] >= 3 * 20 * 0.9           # ... of each rank's OWN time (rank 1 sleeps twice as long)
+    assert dup0 == ([] if n_images != 7 else ["fake-gpu-0"])                    # two ranks on one device are noticed
     assert lo0 == 0 and hi0 == lo1 and hi1 == n_images          # contiguous blocks that cover the batch
     assert tot0 == tot1 == n_images
     assert owned0 == owned1 and all(v in (1, 2) for v in owned0)  # every image owned by exactly one rank
     assert e0 == e1                                                # both ranks report the max over ranks
     assert e0 >= 3 * 0.02 * 0.9                                    # ... which is the slow rank's time
+
+
+def _worker8(rank, world, port, out_q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    from picha_amd.shard import duplicate_devices, rank_report, shard_range, timed_region
+    res = {}
+    for name, n_images in (("cfg4", 2048), ("cfg5", 1024)):   # BASELINE.json configs[3] / [4]: 256 / 128 images per GPU on 8 GPUs
+        lo, hi = shard_range(n_images, rank, world)
+        owned = torch.zeros(n_images, dtype=torch.int64)
+        owned[lo:hi] = 1
+        dist.all_reduce(owned, op=dist.ReduceOp.SUM)
+        res[name] = (lo, hi, bool((owned == 1).all()))
+    local = []
+    elapsed = timed_region(lambda: None, steps=2, sync=lambda: None, dist=dist, local_out=local)
+    seen, ms, devs = rank_report(dist, "cpu", local[0], "gpu-%d" % rank)
+    out_q.put((rank, res, elapsed, seen, len(ms), devs, duplicate_devices(devs)))
+    dist.destroy_process_group()
+
+
+def test_eight_rank_sharding_of_the_baseline_batches_and_the_rank_report():
+    """The 8-GPU launch shape of BASELINE.json configs[3] (2048 x 4K rgba) and configs[4] (1024 x 8K r16g16b16a16), rehearsed with
+    eight gloo ranks on CPU: contiguous blocks of 256 / 128 images that partition the batch, and the fields that make the first
+    real SCALE line self-checking — ranks_seen == 8, one time and one distinct device per rank."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker8, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, res, elapsed, seen, n_ms, devs, dup in results:
+        assert res["cfg4"] == (256 * rank, 256 * (rank + 1), True)
+        assert res["cfg5"] == (128 * rank, 128 * (rank + 1), True)
+        assert seen == world and n_ms == world and devs == ["gpu-%d" % r for r in range(world)] and dup == []
+    assert len({r[2] for r in results}) == 1    # one max-over-ranks time

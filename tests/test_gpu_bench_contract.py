@@ -27,7 +27,10 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and d["unit"] == "Mpix/s"
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["config"]["parity_max_code_diff_vs_oracle_image0"] == 0          # bit-exact default flavour
+    assert d["config"]["parity_max_code_diff_vs_oracle_first2_images_all_ranks"] == 0   # first two images per device
+    assert d["config"]["ranks_seen"] == 1 and len(d["config"]["per_rank_ms"]) == 1 and len(d["config"]["per_rank_device"]) == 1
     r = d["roofline"]
+    assert r["min_launch_ms"] <= r["median_launch_ms"] <= r["max_launch_ms"] and r["median_frac"] > 0
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     assert r["algorithmic_bytes_per_launch"] == 8 * (3840 * 2160 * 4 + 1920 * 1080 * 4)
@@ -70,6 +73,9 @@ def test_bench_two_ranks_over_gloo_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["parallelism"] == "image-sharded x2"
     assert d["config"]["images_per_gpu"] == 8
+    # the self-check of a multi-rank line: both ranks joined, each with its own time; under gloo they share the one GPU
+    assert d["config"]["ranks_seen"] == 2 and len(d["config"]["per_rank_ms"]) == 2 and len(set(d["config"]["per_rank_device"])) == 1
+    assert d["config"]["parity_max_code_diff_vs_oracle_first2_images_all_ranks"] == 0
     # whole-job value: both ranks' images over the max-over-ranks time
     assert abs(d["value"] - 2 * 8 * 3840 * 2160 * 3 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 0.01
     assert d["config"]["parity_max_code_diff_vs_oracle_image0"] == 0

@@ -23,7 +23,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "sym", "block_waves", "xch"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "sym", "block_waves", "xch", "run_phase", "run_xch"):
         set_opt(k, 0)
 
 
@@ -114,21 +114,26 @@ def test_cfg5_full_size_16bit_mitchel():
     n = 3
     src = DeviceBatch(n, 7680, 4320, "r16g16b16a16").fill_random(5)
     sums = {}
-    # planner's choice (r03: the neighbour-exchange accumulator kernel), the one-output accumulator kernel it replaced
-    # (xch = 2), LDS-ring span kernel, two-pass
-    for path, xch in ((0, 0), (4, 2), (3, 0), (1, 0)):
+    # planner's choice (r04: the neighbour-exchange run kernel with wave-uniform weights; 3 images are too few for its time-phased
+    # stores, so the phased form is forced as well), the r03 neighbour-exchange accumulator kernel it replaced (xch = 1), the
+    # one-output accumulator kernel before that (xch = 2), LDS-ring span kernel, two-pass
+    for path, xch, phase in ((0, 0, 0), (0, 0, 12), (0, 1, 0), (4, 2, 0), (3, 0, 0), (1, 0, 0)):
         set_opt("path", path)
         set_opt("xch", xch)
+        set_opt("run_phase", phase)
         out = resize_batch(src, 1920, 1080, filter="mitchel")
         torch.cuda.synchronize()
         name = N.lib().picha_hip_last_kernel().decode()
-        if path == 0:
-            assert name.startswith("resize_acc<ch4,u16,P2,S4,TX15,NACC4,exact,xch"), name   # the kernel bench.py times for cfg5
+        if path == 0 and xch == 0:
+            assert name.startswith("resize_run<ch4,u16,Q1,PX4,TX15,P2,NACC4,exact,bw4,xch5") and ("phased12" in name) == (phase == 12), name   # the kernel bench.py times for cfg5
             planner = out
+        if path == 0 and xch == 1:
+            assert name.startswith("resize_acc<ch4,u16,P2,S4,TX15,NACC4,exact,xch"), name
         if path == 4:
             assert name.startswith("resize_acc<ch4,u16,TX16,NACC4"), name
-        sums[path] = digest(out)
+        sums[(path, xch, phase)] = digest(out)
     set_opt("xch", 0)
+    set_opt("run_phase", 0)
     assert len(set(sums.values())) == 1, sums
     for i in (0, n - 1):
         exp = oracle_resize(src.image_host(i), 1920, 1080, "mitchel", 1.0)
@@ -144,7 +149,8 @@ def test_cfg5_per_gpu_batch_of_128_images_kernel_families_agree():
     set_opt("path", 0)
     a = resize_batch(src, 1920, 1080, filter="mitchel")
     torch.cuda.synchronize()
-    assert N.lib().picha_hip_last_kernel().decode().startswith("resize_acc<ch4,u16,P2,S4,TX15,NACC4,exact,xch")   # persistent launch at this size
+    name = N.lib().picha_hip_last_kernel().decode()
+    assert name.startswith("resize_run<ch4,u16,Q1,PX4,TX15,P2,NACC4,exact,bw4,xch5,phased12"), name   # time-phased stores at this size
     da = digest(a)
     set_opt("path", 3)
     b = resize_batch(src, 1920, 1080, filter="mitchel", out=a)   # reuse the destination batch

@@ -17,7 +17,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up", "run", "run_round"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up", "run", "run_round", "run_xch", "run_ws", "run_phase"):
         set_opt(k, 0)
 
 
@@ -98,6 +98,9 @@ def test_random_resizes_match_oracle(seed):
         set_opt("acc_p2", int(rng.choice([0, 0, 1, 2])))
         set_opt("rows", int(rng.choice([0, 0, 1, 2])))
         set_opt("xch", int(rng.choice([0, 0, 1, 2])))      # neighbour-exchange forms (r03)
+        set_opt("run_xch", int(rng.choice([0, 1, 1, 2])))  # ... of the run kernel (r04), scalar phase weights, time-phased stores
+        set_opt("run_ws", int(rng.choice([0, 0, 2])))
+        set_opt("run_phase", int(rng.choice([0, -1, 5, 9, 12, 20])))
         set_opt("work", int(rng.choice([0, 0, 1, 2, 3])))  # explicit item list / persistent launch / plain grid (r03)
         set_opt("up", int(rng.choice([0, 1, 2])))          # upscales on the accumulator kernel or the span kernel (r03)
         try:
@@ -240,6 +243,8 @@ def test_random_device_batches_match_oracle(seed):
     stream = torch.cuda.current_stream().cuda_stream
     set_opt("work", int(rng.choice([0, 1, 2, 3])))   # item lists / persistent launches index images through the pointer tables
     set_opt("xch", int(rng.choice([0, 1, 2])))
+    set_opt("run_xch", int(rng.choice([0, 1, 2])))
+    set_opt("run_phase", int(rng.choice([0, 5, 12, 20])))
     set_opt("up", int(rng.choice([0, 1, 2])))
     if chain_to:
         N.check(L.picha_hip_convert_resize_device(n, S, D, order, r, g, b, ftag, fscale, stream))

@@ -646,7 +646,7 @@ def test_kernel_selection_for_the_baseline_workloads():
         ("rgba", 384, 216, 192, 108, {"filter": "cubic"}, "resize_stream<ch4,u8,P2,SX2,TX7,SY2,TY7"),     # cfg2, 7 taps
         ("grey", 3840, 216, 512, 51, {"filter": "lanczos"}, "resize_run<ch1,u8,Q2,PX15,TX30,P4,NACC"),   # cfg3b (x: 7.5x = period 2 / 15 pixels, y: 4.2x): run kernel (r03; was the row-staged kernel)
         ("grey", 3584, 216, 512, 51, {"filter": "lanczos"}, "resize_rows<src ch1u8,ch1,u8,P2,S7,TX32"),   # 7x, 28 taps: no run-kernel instantiation, the row-staged kernel
-        ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_acc<ch4,u16,P2,S4,TX15,NACC4,exact,xch"),   # cfg5: neighbour-exchange accumulator kernel (r03)
+        ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_run<ch4,u16,Q1,PX4,TX15,P2,NACC4,exact,bw2,xch5> + resize_edges<4 columns>"),   # cfg5: neighbour-exchange run kernel, wave-uniform weights (r04; r03: resize_acc<...,xch>)
         ("r16", 320, 180, 640, 360, {}, "resize_up<ch1,u16,F2,TX3,P8,exact"),                            # 2x upscale: register-ring kernel (r03)
         ("rgb", 320, 180, 640, 360, {}, "resize_up<ch3,u8,F2,TX3,P4,exact"),
         ("r16", 320, 180, 960, 540, {}, "resize_acc<ch1,u16,P4,S0,TX"),                                  # 3x upscale (not bit-periodic): accumulator kernel, four outputs per lane (r03)
@@ -1053,3 +1053,77 @@ def test_integer_upscales_on_the_accumulator_kernel_match_oracle(pixel, filt):
                 assert names[0].startswith("resize_acc") and ",S0," in names[0], names
     finally:
         set_opt("up", 0)
+
+
+def test_per_call_numerics_override_the_process_option():
+    """r04 (VERDICT r03 missing 4): picha_hip_resize_ex / _device_ex take the numerics flavour per call (picha_call_opts), like the
+    reference's per-call options (src/resize.cc:173-198); the process-wide option is only the default."""
+    from picha_amd.device import DeviceBatch, resize_batch
+    import torch
+    rng = np.random.default_rng(404)
+    img = rand_image(rng, 1920, 216, "rgba")
+    want = oracle_resize(img, 960, 108)
+    opts = {"width": 960, "height": 108}
+    try:
+        for glob in (0, 1):
+            set_opt("numerics", glob)
+            exact = picha_amd.resizeSync(img, opts, numerics="exact")
+            assert ",exact" in N.lib().picha_hip_last_kernel().decode() and max_code_diff(exact, want) == 0
+            fma = picha_amd.resizeSync(img, opts, numerics="fma")
+            assert ",fma" in N.lib().picha_hip_last_kernel().decode() and max_code_diff(fma, want) <= 1
+            dflt = picha_amd.resizeSync(img, opts)
+            assert (",fma" if glob else ",exact") in N.lib().picha_hip_last_kernel().decode()
+            assert max_code_diff(dflt, want) <= glob
+        set_opt("numerics", 1)
+        src = DeviceBatch(3, 1920, 216, "rgba").fill_random(9)
+        out = resize_batch(src, 960, 108, numerics="exact")
+        torch.cuda.synchronize()
+        assert ",exact" in N.lib().picha_hip_last_kernel().decode()
+        for i in range(3):
+            assert np.array_equal(out.image_host(i).pixels(), oracle_resize(src.image_host(i), 960, 108).pixels())
+        # malformed options are refused
+        import ctypes
+        bad = N.CCallOpts(0); bad.numerics = 7
+        s, d = src.descriptors(), out.descriptors()
+        assert N.lib().picha_hip_resize_device_ex(3, s, d, 0, 0.7, ctypes.byref(bad), None) == N.lib().picha_hip_resize_device_ex(3, s, d, 0, 0.7, ctypes.byref(bad), None) != 0
+    finally:
+        set_opt("numerics", 0)
+
+
+def test_work_item_lists_survive_eviction_under_concurrent_callers():
+    """r04: the work-item list cache holds 64 geometries; threads that cycle through more than that while
+    others launch with lists taken just before must never see a freed list (shared ownership, one LRU entry evicted at a time,
+    hipFree outside the lock).  Every result is checked against the oracle."""
+    import threading
+    from picha_amd.device import DeviceBatch, resize_batch
+    import torch
+    set_opt("work", 1)
+    errors = []
+    src = DeviceBatch(2, 1024, 256, "rgba").fill_random(77)
+    hosts = [src.image_host(i) for i in range(2)]
+
+    def worker(t):
+        try:
+            torch.cuda.set_device(0)
+            stream = torch.cuda.Stream()
+            with torch.cuda.stream(stream):
+                for k in range(40):
+                    dh = 40 + ((7 * k + 13 * t) % 80)        # 80 distinct output heights: more keys than the cache holds
+                    out = resize_batch(src, 512, dh)
+                    stream.synchronize()
+                    i = k & 1
+                    exp = oracle_resize(hosts[i], 512, dh)
+                    if not np.array_equal(out.image_host(i).pixels(), exp.pixels()):
+                        errors.append((t, k, dh))
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    try:
+        ts = [threading.Thread(target=worker, args=(t,)) for t in range(6)]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        assert not errors, errors[:5]
+    finally:
+        set_opt("work", 0)
