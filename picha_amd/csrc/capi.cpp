@@ -1447,8 +1447,11 @@ struct ChainEpilogue { float r, g, b; bool force; };
 // -> rgba: -21 % against resize_sym + convert) and rgba at 2x / 3x (-1 .. -3 %: a tie in time, one intermediate image less in
 // HBM); rgb sources lose 10 % (their two-kernel chain runs the four-outputs-per-lane streaming kernel) and at 4x it is a tie,
 // so those keep the chain.  "fuse" = 1 takes the epilogue wherever it exists.
+// r04 (profiles/r04_ab_sym_epilogue.txt): at 2x with 5 taps the epilogue now sits on the symmetric-table kernel (rgba -> grey -8 % / fma -20 %,
+// -> rgb -5 %, r16g16b16a16 -> rgba -17 %); rgba with 7 taps stays a chain (the accumulator kernel's epilogue is 5 % behind
+// resize_stream + convert there).
 bool epilogue_preferred(int pixel, int taps_bucket) {
-    return pixel >= PICHA_R16 || (pixel == PICHA_RGBA && taps_bucket <= 8);
+    return pixel >= PICHA_R16 || (pixel == PICHA_RGBA && taps_bucket <= 8 && taps_bucket != 7);
 }
 int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, int filter,
                  float fscale, hipStream_t s, const ChainEpilogue *epi = nullptr, bool *epi_used = nullptr) {
@@ -1508,9 +1511,22 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % dal) fused_ok = false;
         if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % 4) src_rows4 = false;
     }
-    if (epi) {  // only the one-output accumulator kernel carries the epilogue
-        if (!fused_ok || opt_path == 1 || opt_path == 3 || opt_acc == 2 || s0.width < d0.width || s0.height < d0.height) return PICHA_OK;
-        opt_up = 2; opt_xch = 2; opt_acc_p2 = 2; opt_per_lane = 1; opt_path = 4; opt_work = 3;
+    // resize -> colorConvert as a store epilogue: on the symmetric-table kernel where an instantiation exists for the planner's own
+    // outputs-per-lane choice (r04: 8-bit rgba / rgb at 2x — the shapes whose chain used to be resize_sym + a convert kernel), else on
+    // the one-output accumulator kernel (r03)
+    int epi_sym_pl = 0;
+    if (epi) {
+        if (!fused_ok || opt_path == 1 || opt_path == 3 || s0.width < d0.width || s0.height < d0.height) return PICHA_OK;
+        if (opt_path == 0 && opt_sym != 2 && opt_dpp != 1 && opt_rot == 0 && s0.width % d0.width == 0 && s0.height % d0.height == 0) {
+            const int sx = s0.width / d0.width, sy = s0.height / d0.height;
+            const int pl = opt_per_lane > 0 ? (int)opt_per_lane : sym_preferred_per_lane(pixel, sx, ax->host.taps, fma);
+            if (pl > 0 && sym_epi_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps)) epi_sym_pl = pl;
+        }
+        opt_up = 2; opt_xch = 2;
+        if (!epi_sym_pl) {
+            if (opt_acc == 2) return PICHA_OK;
+            opt_acc_p2 = 2; opt_per_lane = 1; opt_path = 4; opt_work = 3;
+        }
     }
     int per_lane = 1, step = 1, ktaps = fused_x_bucket(ax->host.taps, pixel);  // includes alignment room where needed
     const DeviceAxis::XTable *xt = nullptr;
@@ -1551,7 +1567,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
     }
     // upscales by >= 2 of the 8-bit sub-dword formats (rgb, grey, greya): four outputs per lane sharing one window, whole-dword
     // stores (the one-output-per-lane span kernel is bound by its 1-3 byte stores: 0.15-0.26 of the roof, r01 survey)
-    if (fused_ok && !yr && (opt_per_lane == 0 || opt_per_lane == 4) && opt_path != 4 && opt_path != 1 && kBytes[pixel] % 4 != 0 && pixel < PICHA_R16 &&
+    if (fused_ok && !yr && !epi && (opt_per_lane == 0 || opt_per_lane == 4) && opt_path != 4 && opt_path != 1 && kBytes[pixel] % 4 != 0 && pixel < PICHA_R16 &&
         d0.width >= 2 * s0.width) {
         bool dword_rows = true;
         for (int i = 0; i < n; ++i)
@@ -1564,7 +1580,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             if (cx->ok) { xt = cx; per_lane = 4; step = 0; ktaps = kt; }
         }
     }
-    if (fused_ok && !xt && !yr && opt_per_lane != 1 && opt_path != 4) {
+    if (fused_ok && !xt && !yr && !epi && opt_per_lane != 1 && opt_path != 4) {
         // integer decimation / interpolation step of the tap windows
         const int st = std::max(1, (int)std::lround((double)s0.width / d0.width));
         static const int cand[] = {2, 4};
@@ -1632,6 +1648,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 p.block_waves = bw;
                 p.sync_steps = opt_sym_sync == 1 ? 1 : 0;
                 p.xch = xch ? 1 : 0;
+                if (epi) { p.epi_on = 1; p.epi_pixel = d0.pixel; p.epi_r = epi->r; p.epi_g = epi->g; p.epi_b = epi->b; }
             }
             const long long col_waves = (cx->groups + 63) / 64;
             // row chunks: at least ~32 K waves per launch, chunks of >= 16 output rows.  Every chunk re-reads and
@@ -1705,7 +1722,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
         if (opt_sym != 2 && opt_dpp != 1 && opt_rot == 0) {
             // outputs per lane: the measured best for this (format, scale, taps, flavour), or what "per_lane" forces
             const int pref = sym_preferred_per_lane(pixel, sx, ax->host.taps, fma);
-            const int cand_sym[5] = {opt_per_lane > 0 ? (int)opt_per_lane : pref, 0, 0, 0, 0};
+            const int cand_sym[5] = {epi ? epi_sym_pl : opt_per_lane > 0 ? (int)opt_per_lane : pref, 0, 0, 0, 0};
             for (int pl : cand_sym) {
                 if (pl == 0) break;
                 if (opt_per_lane > 0 && pl != opt_per_lane) continue;
@@ -1737,11 +1754,17 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 // 4 as with 2, 2.184 vs 2.186 ms on cfg2, and 4 keeps the fabric traffic at 1.09x instead of 1.14x: profiles/r03_ab_work_items.txt)
                 const bool big = (long long)n * ((cx->groups + 63) / 64) * std::max(1, d0.height / 60) >= 6144 && opt_work != 3;
                 const int bw = opt_bw > 0 ? (int)std::min<long>(opt_bw, 4) : (fma || big ? 4 : 2);
+                if (epi && epi_used) *epi_used = true;
                 return launch_stream(pl, cx, cy, 0, false, true, bw, xch);
             }
         }
+        if (epi) {   // no symmetric-table launch after all: the accumulator kernel's epilogue, or the caller's two-kernel chain
+            if (opt_acc == 2) return PICHA_OK;
+            opt_acc_p2 = 2; opt_per_lane = 1; opt_path = 4; opt_work = 3;
+        }
         bool want_dpp = opt_dpp == 1 && stream_dpp_supported(pixel, sx, ax->host.taps, sy, ay->host.taps);
         for (int pl : cand_s) {
+            if (epi) break;   // the general streaming kernels carry no epilogue
             if (want_dpp && pl != 1) continue;
             if (!want_dpp) {
                 if (opt_per_lane > 0 && pl != opt_per_lane) continue;

@@ -188,11 +188,15 @@ struct StreamParams {
     int sync_steps;   // 1: one s_barrier per step keeps a workgroup's waves in lockstep (shared edge lines hit in L1)
     int xch;          // 1: neighbour-exchange variant (a lane loads only its own x_step * x_per_lane pixels; uniform-base x table)
     WorkList work;    // resize_sym_kernel only: explicit work items / persistent launch
+    // resize_sym_kernel, colour-convert epilogue (r04; as FusedParams::epi_*): dst_* describe the converted image
+    int epi_on, epi_pixel;
+    float epi_r, epi_g, epi_b;
 };
 bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot);
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty);
 bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int xch = 0);
+bool sym_epi_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty);   // colour-convert epilogue instantiation
 hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 // workgroups of the persistent form the device holds at once for the configuration in p (0: no such instantiation)
 int sym_kernel_resident_blocks(int pixel, const StreamParams &p);

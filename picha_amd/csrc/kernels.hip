@@ -25,6 +25,7 @@ PICHA_DECL_STREAM(4) PICHA_DECL_STREAM(5) PICHA_DECL_STREAM(6) PICHA_DECL_STREAM
 // defined in kernels_sym.hip, one translation unit per pixel format
 #define PICHA_DECL_SYM(N)                                                                \
     bool sym_supported_pixel##N(int per_lane, int sx, int tx, int sy, int ty, int xch);   \
+    bool sym_epi_supported_pixel##N(int per_lane, int sx, int tx, int sy, int ty);        \
     hipError_t launch_sym_pixel##N(const StreamParams &p, hipStream_t s, const char **name); \
     int sym_resident_pixel##N(const StreamParams &p);
 PICHA_DECL_SYM(0) PICHA_DECL_SYM(1) PICHA_DECL_SYM(2) PICHA_DECL_SYM(3)
@@ -88,6 +89,14 @@ int run_kernel_resident_blocks(int pixel, const RunParams &p) {
     return n;
 }
 
+bool sym_epi_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return sym_epi_supported_pixel##N(per_lane, sx, tx, sy, ty);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return false;
+}
 bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int xch) {
     switch (pixel) {
 #define PICHA_CASE(N) case N: return sym_supported_pixel##N(per_lane, sx, tx, sy, ty, xch);
@@ -258,6 +267,8 @@ bool acc_xch_supported(int pixel, int per_lane, int step, int taps, int nacc) {
     const int bpp = pixel_channels(pixel) * (pixel_is16(pixel) ? 2 : 1);
     return pixel >= 0 && pixel <= 7 && bpp % 4 == 0 && (nacc == 4 || nacc == 6) && acc_xch_shape(per_lane, step, taps);
 }
+PICHA_PROBE_HOST(picha_probe_kernels)
+
 bool acc_supported(int pixel, int x_taps_bucket, int nacc) {
     if (pixel < 0 || pixel > 7 || (nacc != 4 && nacc != 6)) return false;
     if (x_taps_bucket > 36) {  // resize_acc_long_kernel: multiples of half a segment

@@ -572,6 +572,7 @@ __global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
     static_assert(P % F == 0, "a lane owns whole periods");
     constexpr int NRAW = C::NW;
     constexpr int NB = 4;  // row buffers; K is a multiple of it: one unrolled group of K rows
+    PICHA_PROBE_BEGIN
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
@@ -741,6 +742,7 @@ __global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
         if (r + KK <= r1) process_row(raw[KK % NB], r + KK, k_c);
     };
     for (int r = r0; r <= r1; r += K) unroll_steps<K>(r, step);
+    PICHA_PROBE_END
 }
 
 template <int CH, bool S16, int Q, int PX, int TX, int P, int RC, int K, int TYM>
@@ -837,11 +839,20 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #ifndef PICHA_RUN_PIXEL
 #error "compile with -DPICHA_RUN_PIXEL=0..7"
 #endif
+#ifdef PICHA_RUN_EXPERIMENT   // developer shortcut: ONE shape (seconds instead of minutes), e.g. -DPICHA_RUN_PIXEL=2 '-DPICHA_RUN_EXPERIMENT=Z(2,15,30,8,1,-1,1)'
+#define PICHA_RUN_LIST_X(X)
+#define PICHA_UP_LIST_X(U)
+#define PICHA_RUNZ_LIST_X(Z) PICHA_RUN_EXPERIMENT
+#undef PICHA_RUN_PIXEL_LISTS
+#define PICHA_RUN_PIXEL_LISTS X
+#else
+#define PICHA_RUN_PIXEL_LISTS PICHA_RUN_PIXEL
+#endif
 #define PICHA_CAT2(a, b) a##b
 #define PICHA_CAT(a, b) PICHA_CAT2(a, b)
-#define PICHA_RUN_LIST PICHA_CAT(PICHA_RUN_LIST_, PICHA_RUN_PIXEL)
-#define PICHA_RUNZ_LIST PICHA_CAT(PICHA_RUNZ_LIST_, PICHA_RUN_PIXEL)
-#define PICHA_UP_LIST PICHA_CAT(PICHA_UP_LIST_, PICHA_RUN_PIXEL)
+#define PICHA_RUN_LIST PICHA_CAT(PICHA_RUN_LIST_, PICHA_RUN_PIXEL_LISTS)
+#define PICHA_RUNZ_LIST PICHA_CAT(PICHA_RUNZ_LIST_, PICHA_RUN_PIXEL_LISTS)
+#define PICHA_UP_LIST PICHA_CAT(PICHA_UP_LIST_, PICHA_RUN_PIXEL_LISTS)
 
 PICHA_PROBE_HOST(PICHA_CAT(picha_probe_run_p, PICHA_RUN_PIXEL))
 

@@ -13,6 +13,8 @@ namespace picha_hip {
 hipError_t PICHA_CAT(launch_span_p1_pixel, PICHA_SPAN_PIXEL)(const FusedParams &p, hipStream_t s, const char **name) {
     return launch_span_p1<pixel_channels(PICHA_SPAN_PIXEL), pixel_is16(PICHA_SPAN_PIXEL)>(p, s, name);
 }
+PICHA_PROBE_HOST(PICHA_CAT(picha_probe_span_p, PICHA_SPAN_PIXEL))
+
 hipError_t PICHA_CAT(launch_acc_p1_pixel, PICHA_SPAN_PIXEL)(const FusedParams &p, hipStream_t s, const char **name) {
     return launch_acc_p1<pixel_channels(PICHA_SPAN_PIXEL), pixel_is16(PICHA_SPAN_PIXEL)>(p, s, name);
 }

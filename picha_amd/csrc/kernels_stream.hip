@@ -13,6 +13,8 @@ namespace picha_hip {
 #define PICHA_CAT(a, b) PICHA_CAT2(a, b)
 #define PICHA_STREAM_LIST PICHA_CAT(PICHA_STREAM_LIST_, PICHA_STREAM_PIXEL)
 
+PICHA_PROBE_HOST(PICHA_CAT(picha_probe_stream_p, PICHA_STREAM_PIXEL))
+
 bool PICHA_CAT(stream_supported_pixel, PICHA_STREAM_PIXEL)(int per_lane, int sx, int tx, int sy, int ty, int rot) {
 #define X(CH, S16, P, SX, TX, SY, TY, ROT) if (per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY && (rot != 0) == ROT) return true;
     PICHA_STREAM_LIST(X)

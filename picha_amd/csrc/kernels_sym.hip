@@ -30,7 +30,10 @@ template <int CH, bool S16, int P, int SX, int TX, bool XCH> constexpr int sym_n
     return (XCH ? XchCfg<CH, S16, P, SX, TX>::NOWN + XchCfg<CH, S16, P, SX, TX>::NE : SpanCfg<CH, S16, P, SX, TX>::NW) <= 12 ? 3 : 2;
 }
 
-template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA, bool XCH = false>
+// EPI (r04): the colour convert of a resize -> colorConvert chain as a STORE EPILOGUE (as on the accumulator kernel since r03,
+// epilogue_store in kernels_impl.inc): the finished pixel is packed to the resize's own sample type exactly as src/resize.cc:130
+// writes it, unpacked, channel-mapped and packed to p.epi_pixel (src/colorconvert.cc:143-150); dst_* describe THAT image.
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA, bool XCH = false, bool EPI = false>
 __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
     using C = SpanCfg<CH, S16, P, SX, TX>;
     using X = XchCfg<CH, S16, P, SX, TX>;
@@ -189,7 +192,13 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
                     const int y = m - ICLOSE;
                     if (y >= y0) {  // outputs above the chunk belong to the previous chunk
                         const int sl = ((ICLOSE - K) % NPEND + NPEND) % NPEND;
-                        store_lane_outputs<C, CH, S16, P, FMA>(acc[sl], dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
+                        if constexpr (EPI) {
+#pragma unroll
+                            for (int o = 0; o < P; ++o)
+                                if (x0 + o < p.dst_w) epilogue_store<CH, S16>(acc[sl][o], p.epi_pixel, p.epi_r, p.epi_g, p.epi_b, dst_rs, y, x0 + o, p.dst_stride);
+                        } else {
+                            store_lane_outputs<C, CH, S16, P, FMA>(acc[sl], dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
+                        }
                     }
                 }
             }
@@ -223,15 +232,17 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
     PICHA_PROBE_END
 }
 
-template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool XCH = false>
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool XCH = false, bool EPI = false>
 hipError_t launch_sym_t(const StreamParams &p, hipStream_t s, const char **name) {
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 2;
     dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
     if (p.work.items) grid = dim3(p.work.queue ? (unsigned)p.n_chunks : 8u * (unsigned)p.work.items_per_xcd, 1, 1);  // persistent: n_chunks = resident workgroups
-    if (p.fma) resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true, XCH><<<grid, 64 * bw, 0, s>>>(p);
-    else resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false, XCH><<<grid, 64 * bw, 0, s>>>(p);
-    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_sym<ch%d,%s,P%d,SX%d,TX%d,SY%d,TY%d,%s,bw%d%s%s>", CH, S16 ? "u16" : "u8", P, SX, TX, SY,
-             TY, p.fma ? "fma" : "exact", bw, XCH ? ",xch" : "", p.work.queue ? ",persistent" : p.work.items ? ",items" : "");
+    if (p.fma) resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true, XCH, EPI><<<grid, 64 * bw, 0, s>>>(p);
+    else resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false, XCH, EPI><<<grid, 64 * bw, 0, s>>>(p);
+    char epi[40] = "";
+    if (EPI) snprintf(epi, sizeof epi, ",epilogue -> %s", kPixelNameAll[p.epi_pixel & 7]);
+    snprintf(g_kernel_name, sizeof g_kernel_name, "resize_sym<ch%d,%s,P%d,SX%d,TX%d,SY%d,TY%d,%s,bw%d%s%s%s>", CH, S16 ? "u16" : "u8", P, SX, TX, SY,
+             TY, p.fma ? "fma" : "exact", bw, XCH ? ",xch" : "", epi, p.work.queue ? ",persistent" : p.work.items ? ",items" : "");
     if (name) *name = g_kernel_name;
     return hipGetLastError();
 }
@@ -277,6 +288,18 @@ int sym_resident_t(const StreamParams &p) {
 #define PICHA_SYMX_LIST_6(Y)
 #define PICHA_SYMX_LIST_7(Y) /* r16g16b16a16 */ Y(2, 2, 5, 2, 5)
 
+// Colour-convert epilogue instantiations: E(P, SX, TX, SY, TY) — resize -> colorConvert of 8-bit rgba (and rgb in the fma flavour, whose
+// planner choice at 2x is this kernel) at 2x, picha's default 5 taps and the 7 taps of {filter: ...}: the shapes whose two-kernel chain
+// ran resize_sym + a convert (r03: the epilogue existed on the one-output accumulator kernel only)
+#define PICHA_SYME_LIST_0(E) /* rgb */ E(4, 2, 5, 2, 5)
+#define PICHA_SYME_LIST_1(E) /* rgba */ E(3, 2, 5, 2, 5)   /* 7 taps (P2, fma) measured 2-5 % behind the two-kernel chain: not instantiated */
+#define PICHA_SYME_LIST_2(E)
+#define PICHA_SYME_LIST_3(E)
+#define PICHA_SYME_LIST_4(E)
+#define PICHA_SYME_LIST_5(E)
+#define PICHA_SYME_LIST_6(E)
+#define PICHA_SYME_LIST_7(E) /* r16g16b16a16 */ E(2, 2, 5, 2, 5)
+
 }  // namespace
 
 #ifndef PICHA_SYM_PIXEL
@@ -286,6 +309,14 @@ int sym_resident_t(const StreamParams &p) {
 #define PICHA_CAT(a, b) PICHA_CAT2(a, b)
 #define PICHA_SYM_LIST PICHA_CAT(PICHA_SYM_LIST_, PICHA_SYM_PIXEL)
 #define PICHA_SYMX_LIST PICHA_CAT(PICHA_SYMX_LIST_, PICHA_SYM_PIXEL)
+#define PICHA_SYME_LIST PICHA_CAT(PICHA_SYME_LIST_, PICHA_SYM_PIXEL)
+
+bool PICHA_CAT(sym_epi_supported_pixel, PICHA_SYM_PIXEL)(int per_lane, int sx, int tx, int sy, int ty) {
+#define E(P, SX, TX, SY, TY) if (per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY) return true;
+    PICHA_SYME_LIST(E)
+#undef E
+    return false;
+}
 
 PICHA_PROBE_HOST(PICHA_CAT(picha_probe_sym_p, PICHA_SYM_PIXEL))
 
@@ -315,6 +346,12 @@ int PICHA_CAT(sym_resident_pixel, PICHA_SYM_PIXEL)(const StreamParams &p) {
 }
 
 hipError_t PICHA_CAT(launch_sym_pixel, PICHA_SYM_PIXEL)(const StreamParams &p, hipStream_t s, const char **name) {
+#define E(P, SX, TX, SY, TY)                                                                                          \
+    if (p.epi_on && !p.xch && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY) \
+        return launch_sym_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY, false, true>(p, s, name);
+    PICHA_SYME_LIST(E)
+#undef E
+    if (p.epi_on) return hipErrorInvalidValue;
 #define Y(P, SX, TX, SY, TY)                                                                                          \
     if (p.xch && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY)           \
         return launch_sym_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY, true>(p, s, name);

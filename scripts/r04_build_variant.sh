@@ -19,6 +19,25 @@ for n in 0 1 2 3 4 5 6 7; do
     symobjs="$symobjs build/var_$tag/sym_p$n.o"
   else symobjs="$symobjs build/sym_p$n.o"; fi
 done
+streamobjs=""
+for n in 0 1 2 3 4 5 6 7; do
+  if [[ " $STREAM_PIX " == *" $n "* ]]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize -DPICHA_STREAM_PIXEL=$n $flags -c kernels_stream.hip -o build/var_$tag/stream_p$n.o &
+    streamobjs="$streamobjs build/var_$tag/stream_p$n.o"
+  else streamobjs="$streamobjs build/stream_p$n.o"; fi
+done
+spanobjs=""
+for n in 0 1 2 3 4 5 6 7; do
+  if [[ " $SPAN_PIX " == *" $n "* ]]; then
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize -DPICHA_SPAN_PIXEL=$n $flags -c kernels_span.hip -o build/var_$tag/span_p$n.o &
+    spanobjs="$spanobjs build/var_$tag/span_p$n.o"
+  else spanobjs="$spanobjs build/span_p$n.o"; fi
+done
+kobj=build/kernels.o
+if [ -n "$KERNELS_TU" ]; then
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize $flags -c kernels.hip -o build/var_$tag/kernels.o &
+  kobj=build/var_$tag/kernels.o
+fi
 rowsobjs=""
 for n in 0 1 2 3 4 5 6 7 8 9 10 11; do
   if [[ " $ROWS_VAR " == *" $n "* ]]; then
@@ -27,6 +46,6 @@ for n in 0 1 2 3 4 5 6 7 8 9 10 11; do
   else rowsobjs="$rowsobjs build/rows_v$n.o"; fi
 done
 wait
-rest="$(ls build/*.o | grep -v "build/run_p" | grep -v "build/sym_p" | grep -v "build/rows_v") $symobjs $rowsobjs"
+rest="$(ls build/*.o | grep -v "build/run_p" | grep -v "build/sym_p" | grep -v "build/rows_v" | grep -v "build/stream_p" | grep -v "build/span_p" | grep -v "build/kernels.o") $symobjs $rowsobjs $streamobjs $spanobjs $kobj"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libpicha_hip_$tag.so $rest $objs
 ls -la ../variants/libpicha_hip_$tag.so

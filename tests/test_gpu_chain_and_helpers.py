@@ -616,3 +616,59 @@ def test_run_kernel_scalar_phase_weights_match_oracle(pixel, dw):
     finally:
         for k in (b"run_round", b"run_ws", b"numerics"):
             N.check(N.lib().picha_hip_set_option(k, 0))
+
+
+@pytest.mark.parametrize("case", [
+    ("rgba", "grey", 1920, 216, None), ("rgba", "greya", 1920, 216, None), ("rgba", "rgb", 1920, 216, None), ("rgba", "r16", 1536, 120, None),
+    ("rgb", "grey", 1920, 216, None), ("r16g16b16a16", "rgba", 1536, 120, None), ("r16g16b16a16", "grey", 1536, 120, None),
+], ids=lambda c: "%s-%s-%s" % (c[0], c[1], c[4]))
+def test_resize_then_convert_epilogue_on_the_symmetric_table_kernel(case):
+    """r04: resize -> colorConvert as ONE kernel for the 2x shapes whose chain used to be resize_sym + a convert
+    kernel: the convert is a store epilogue of resize_sym (src/resize.cc:130 then src/colorconvert.cc:143-150).  Against oracle
+    resize -> oracle colorConvert (bit-exact; fma within one code value of the resize's sample type, i.e. <= 1 after an 8-bit
+    convert, more after 16 -> 8 bit luma sums), byte-equal to the two-kernel chain, default and custom luma weights, chunkings."""
+    from picha_amd.device import DeviceBatch, convert_resize_batch
+    import torch
+    src_pixel, dst_pixel, sw, sh, filt = case
+    dw, dh = sw // 2, sh // 2
+    fscale = 1.0 if filt else 0.70
+    n = 3
+    src = DeviceBatch(n, sw, sh, src_pixel).fill_random(31 + sw)
+    keys = (b"fuse", b"row_chunks", b"work", b"numerics")
+    try:
+        custom = picha.color_settings(0.2, 0.5, 0.3)
+        for weights in (None, custom):
+            want = [oracle_convert(oracle_resize(src.image_host(i), dw, dh, filt or "cubic", fscale), dst_pixel, weights=weights) for i in range(n)]
+            if src_pixel == "rgb":   # the symmetric-table kernel serves rgb at 2x in the fma flavour only (reference arithmetic: resize_stream)
+                continue
+            for chunks, work in ((0, 0), (3, 3), (2, 1)):
+                N.check(N.lib().picha_hip_set_option(b"fuse", 1))
+                N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
+                N.check(N.lib().picha_hip_set_option(b"work", work))
+                out = convert_resize_batch(src, dst_pixel, dw, dh, filter=filt, order=1, weights=weights)
+                torch.cuda.synchronize()
+                name = N.lib().picha_hip_last_kernel().decode()
+                assert name.startswith("resize_sym<") and ("epilogue -> %s" % dst_pixel) in name, name
+                for i in range(n):
+                    assert np.array_equal(out.image_host(i).pixels(), want[i].pixels()), (case, weights, chunks, work, i, name)
+            N.check(N.lib().picha_hip_set_option(b"row_chunks", 0))
+            N.check(N.lib().picha_hip_set_option(b"work", 0))
+            N.check(N.lib().picha_hip_set_option(b"fuse", 2))     # the two-kernel chain: byte-equal
+            two = convert_resize_batch(src, dst_pixel, dw, dh, filter=filt, order=1, weights=weights)
+            torch.cuda.synchronize()
+            assert "epilogue" not in N.lib().picha_hip_last_kernel().decode()
+            for i in range(n):
+                assert np.array_equal(two.image_host(i).pixels(), want[i].pixels())
+        N.check(N.lib().picha_hip_set_option(b"fuse", 1))
+        N.check(N.lib().picha_hip_set_option(b"numerics", 1))
+        out = convert_resize_batch(src, dst_pixel, dw, dh, filter=filt, order=1, weights=custom)
+        torch.cuda.synchronize()
+        name = N.lib().picha_hip_last_kernel().decode()
+        assert "epilogue -> %s" % dst_pixel in name and ",fma" in name, name
+        # one code value of the RESIZE's sample type: an 8-bit step is 257 steps of a 16-bit destination
+        tol = 257 if dst_pixel.startswith("r16") and not src_pixel.startswith("r16") else 1
+        for i in range(n):
+            assert max_code_diff(out.image_host(i), want[i]) <= tol, (case, name)
+    finally:
+        for k in keys:
+            N.check(N.lib().picha_hip_set_option(k, 0))
