@@ -346,20 +346,25 @@ def main():
         ach = alg_bytes / (avg_launch_ms * 1e-3) / 1e9
         # HBM traffic of the dominant kernel: rocprofv3 PMC passes cannot run inside this process, so the figure comes from
         # the committed profile of the same workload — and only if that profile was taken on the kernel that ran here
-        traffic, traffic_source = None, None
-        tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % args.workload)
-        if os.path.exists(tpath):
-            try:
-                rec = json.load(open(tpath))
-                if rec.get("kernel", "").split(" ")[0] == kernel.split(" ")[0]:
-                    traffic = int(rec["hbm_bytes_per_launch"] / rec.get("images_per_launch", 256) * n)
-                    traffic_source = {"file": "profiles/traffic_%s.json" % args.workload, "kernel": rec.get("kernel"),
-                                      "round": rec.get("round"), "ratio_to_algorithmic": rec.get("ratio_to_algorithmic")}
-                else:
-                    traffic_source = {"file": "profiles/traffic_%s.json" % args.workload, "kernel": rec.get("kernel"),
-                                      "stale": "measured on another kernel than the one that ran: traffic withheld"}
-            except Exception:
-                traffic = None
+        def committed_traffic(kernel_name):
+            """(bytes per launch scaled to this batch, provenance) from profiles/traffic_<workload>[.fma].json — whichever was measured on
+            the kernel that ran; provenance alone (marked stale) if only other kernels' profiles exist"""
+            stale = None
+            for suffix in ("", ".fma"):
+                rel = "profiles/traffic_%s%s.json" % (args.workload, suffix)
+                tpath = os.path.join(ROOT, rel)
+                if not os.path.exists(tpath):
+                    continue
+                try:
+                    rec = json.load(open(tpath))
+                except Exception:
+                    continue
+                if rec.get("kernel", "").split(" ")[0] == kernel_name.split(" ")[0]:
+                    return (int(rec["hbm_bytes_per_launch"] / rec.get("images_per_launch", 256) * n),
+                            {"file": rel, "kernel": rec.get("kernel"), "round": rec.get("round"), "ratio_to_algorithmic": rec.get("ratio_to_algorithmic")})
+                stale = {"file": rel, "kernel": rec.get("kernel"), "stale": "measured on another kernel than the one that ran: traffic withheld"}
+            return None, stale
+        traffic, traffic_source = committed_traffic(kernel)
         out = {
             "metric": "Mpix/s batched 4K->1080p rgba cubic resize" if args.workload.startswith("cfg2") else "Mpix/s " + args.workload,
             "value": round(total_px / elapsed / 1e6, 1),
@@ -411,6 +416,8 @@ def main():
         if other is not None:
             other["value_mpix_s"] = round(src_px / (other["avg_launch_ms"] * 1e-3) / 1e6, 1)
             other["roofline_frac"] = round(alg_bytes / (other["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            other["read_only_frac"] = round(read_b / (other["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+            other["traffic"], other["traffic_source"] = committed_traffic(other["kernel"])
             out["other_numerics"] = other
         if world == 1 and not args.no_cpu_baseline and not convert_to:
             out["cpu_baseline"] = cpu_baseline(args.workload)

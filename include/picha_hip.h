@@ -159,6 +159,11 @@ int picha_hip_device_arch(char *buf, size_t len);
  *                with >= 26 taps, their shorter instantiated windows (1.5x .. 8x) for batches of >= 96 images; 2x upscales: every format with an
  *                instantiation), 1 = wherever an instantiation exists, 2 = never.  "per_lane" (2, 4, 8), "row_chunks", "block_waves" and "work" (1, 2; default
  *                plain grid) apply to it too
+ *   "run_xch"    (r04) its neighbour-exchange form for dword-sized pixels at integer scales (a lane loads only the pixels it owns, wave-uniform
+ *                weights, clipped columns recomputed from the image; cfg5's kernel): 0 = auto, 1 = wherever instantiated, 2 = never
+ *   "run_ws"     (r04) the weights of one phase of the period in SGPRs (the 7.5x shapes: four waves per SIMD): 0 = auto, 1 = wherever instantiated, 2 = never
+ *   "run_phase"  (r04) time-phased stores of the neighbour-exchange form (finished rows wait in registers until a chip-wide 100 MHz counter crosses a
+ *                phase boundary): 0 = auto (launches with >= 3 source rows per output row and >= 20 000 image-rows), -1 = off, n = phases of 2^n ticks
  *   "run_round"  its window offsets inside a period: 0 = auto (the rounding with the shorter window), 1 = down, 2 = up
  *                ("run" = 3 is a measurement aid: the run kernel WITHOUT its edge columns — those come out wrong)
  *   "fuse"       picha_hip_convert_resize*: 0 = one fused kernel where it exists and was measured faster (default: every
@@ -180,16 +185,17 @@ int picha_hip_device_arch(char *buf, size_t len);
 int picha_hip_set_option(const char *key, long value);
 long picha_hip_get_option(const char *key);
 /* Name of the kernel instantiation the last device operation on this thread launched (diagnostics, bench JSON):
- *   "resize_sym<...>"        symmetric-table streaming kernel (",xch": neighbour-exchange form; ",items" / ",persistent":
- *                            launched through a work-item list / by persistent workgroups)
+ *   "resize_sym<...>"        symmetric-table streaming kernel (",xch": neighbour-exchange form; ",epilogue -> fmt": colour convert fused in at the
+ *                            store (r04); ",items" / ",persistent": launched through a work-item list / by persistent workgroups)
  *   "resize_stream<...>"     general streaming kernel (",rot": rotating accumulators), "resize_stream_dpp<...>"
  *   "resize_acc<...>"        accumulator kernel ("P2": two outputs per lane, ",xch"; "S0": upscale shape, outputs share one
  *                            window; ",epilogue -> fmt": colour convert fused in at the store), "resize_acc_long<...>" (> 36 taps)
  *   "resize_rows<...>"       row-staged LDS kernel ("src chN -> chM": colour convert fused in)
  *   "resize_up<...> / resize_ring<...> + resize_edges<N columns>"   ring-in-registers kernel: 2x / 4x upscales (F: factor, P outputs
  *                            per lane) / ring-aliased lanczos downscales (K ring rows), and the edge-column kernel
- *   "resize_run<...> + resize_edges<N columns>"   run kernel (Q outputs / PX source pixels per period, P outputs per lane)
- *                            and the kernel that recomputes the N columns whose windows an image edge clips
+ *   "resize_run<...> + resize_edges<N columns>"   run kernel (Q outputs / PX source pixels per period, P outputs per lane; r04: ",xchN" neighbour
+ *                            exchange with N window pixels in front of the lane's own, ",wsN" N phases' weights in SGPRs, ",phasedM" time-phased
+ *                            stores with phases of 2^M x 10 ns) and the kernel that recomputes the N columns whose windows an image edge clips
  *   "resize_span<...>"       LDS-ring span kernel (upscales, ring-aliasing cases)
  *   "twopass"                hpass_generic + vpass_generic through an HBM scratch
  *   "color_convert_wide<a->b,..>", "color_convert_expand<a->b>", "color_convert<a->b,4px>"

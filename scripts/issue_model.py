@@ -6,7 +6,8 @@
       f32 adds 1.37, fused multiply-adds 1.38, conversions 1.69, everything else (moves, DPP, clamps, integer address work) 0.88 .. 2.38
   issue time  = issue ticks / 1024 SIMDs / in-kernel clock
 
-usage: python scripts/issue_model.py <prof summary.txt> <kernel name substring> <in-kernel GHz> [label]
+usage: python scripts/issue_model.py <prof summary.txt> <kernel name substring> <in-kernel GHz> [label [n]]
+       n: which "launches" line of the trace with that kernel prefix gives the time (the trace truncates names: 0 = the headline flavour, 1 = the other)
 """
 import re, sys
 path, want, ghz = sys.argv[1], sys.argv[2], float(sys.argv[3])
@@ -22,11 +23,13 @@ for b in blocks:
         break
 if c is None:
     sys.exit("no counters for a kernel matching %r in %s" % (want, path))
-ms = None
+ms, nth = None, int(sys.argv[5]) if len(sys.argv) > 5 else 0
 for m in re.finditer(r"launches (.*?)n=(\d+)\s+all-launch avg ([0-9.]+) ms\s+median ([0-9.]+) ms\s+last (\d+) launches avg ([0-9.]+) ms", text):
     if want in m.group(1) or want.split("<")[0] in m.group(1):
         ms = float(m.group(6))
-        break
+        if nth == 0:
+            break
+        nth -= 1
 valu = c.get("SQ_INSTS_VALU", 0.0)
 mul, add, fma, cvt = (c.get("SQ_INSTS_VALU_" + k, 0.0) for k in ("MUL_F32", "ADD_F32", "FMA_F32", "CVT"))
 other = max(0.0, valu - mul - add - fma - cvt)
