@@ -126,13 +126,13 @@ def test_reference_arithmetic_kernels_have_no_fused_multiply_add(device_disassem
     checked = fma_flavour = 0
     for name, body in kernels.items():
         # template tails: resize_span_kernel<..., bool FMA>, resize_stream_kernel<..., bool FMA, bool ROT>,
-        # resize_sym_kernel<..., bool FMA, bool XCH>, resize_acc_kernel<..., bool FMA, int P, int S, bool XCH, bool EPI>
+        # resize_sym_kernel<..., bool FMA, bool XCH, bool EPI>, resize_acc_kernel<..., bool FMA, int P, int S, bool XCH, bool EPI>
         m = re.search(r"resize_span_kernelI.*ELb([01])EEEvNS_", name) or \
             re.search(r"resize_acc_long_kernelI.*ELb([01])EEEvNS_", name) or \
             re.search(r"resize_acc_kernelI.*ELb([01])ELi\d+ELi\d+ELb[01]ELb[01]EEEvNS_", name) or \
             re.search(r"resize_stream_kernelI.*ELb([01])ELb[01]EEEvNS_", name) or \
             re.search(r"resize_stream_dpp_kernelI.*ELb([01])EEEvNS_", name) or \
-            re.search(r"resize_sym_kernelI.*ELb([01])ELb[01]EEEvNS_", name) or \
+            re.search(r"resize_sym_kernelI.*ELb([01])ELb[01]ELb[01]EEEvNS_", name) or \
             re.search(r"resize_rows_kernelI.*ELb([01])EEEvNS_", name) or \
             re.search(r"resize_run_kernelI.*ELb([01])ELi[01]ELin?\d+ELi\d+ELi[01]EEEvNS_", name) or \
             re.search(r"resize_ring_kernelI.*ELb([01])ELi[01]EEEvNS_", name)  # run: <..., FMA, RC, XHL, WS, PH>, ring: <..., FMA, RC>; resize_edges_kernel is reference arithmetic only
