@@ -1234,6 +1234,16 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         chunks = std::min(chunks, std::max(by_halo, by_fill));
     }
     chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, opt_chunks > 0 ? d0.height : d0.height / 16)));
+    if (opt_chunks <= 0 && xhl >= 0 && p.phase_shift > 0) {
+        // the neighbour-exchange form with phased stores is bound by its memory pattern: every halo row it re-reads is
+        // time.  Longer chunks — halo under ~3 % — as long as the launch stays at least two rounds of resident workgroups
+        // (cfg5, 32 images: 18 -> 12 chunks 1.922 -> 1.892 ms, fma 1.781 -> 1.732; 9 chunks = 1.4 rounds 2.012; profiles/r04_ab_run_xch.txt)
+        const double src_rows_per_out = std::max(1.0, (double)s0.height / d0.height);
+        const long long by_halo3 = std::max<long long>(1, d0.height / std::max<long long>(16, (long long)std::ceil(ring / (0.03 * src_rows_per_out))));
+        const int resident = run_kernel_resident_blocks(pixel, p);
+        const long long two_rounds = resident > 0 ? (2LL * resident + (long long)nsb * n - 1) / ((long long)nsb * n) : chunks;
+        chunks = std::max<long long>(1, std::min(chunks, std::max(by_halo3, two_rounds)));
+    }
     // small launches (a single image): chunks of down to one row for about 3000 waves, as for the accumulator kernel
     if (opt_chunks <= 0 && (long long)n * col_waves * chunks < 3000)
         chunks = std::max(chunks, std::min<long long>(d0.height, (3000 + (long long)n * col_waves - 1) / ((long long)n * col_waves)));

@@ -396,6 +396,9 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
         int rec[2 * NACC];
 #pragma unroll
         for (int t = 0; t < 2 * NACC; ++t) rec[t] = yrec[(size_t)row * (2 * NACC) + t];
+        // phased stores: the chip-wide clock is read here, with the record, so that its scalar-memory latency passes under the horizontal pass
+        [[maybe_unused]] unsigned long long realtime = 0;
+        if constexpr (PH) realtime = __builtin_amdgcn_s_memrealtime();
         // ---- horizontal pass (src/resize.cc:110-117): every window pixel converted once, used by all outputs it is a tap of ----
         float h[P][CH];
 #if PICHA_RUN_ABLATE == 1
@@ -517,7 +520,7 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
             }
         }
         if constexpr (PH) {
-            const unsigned ph = unsigned(__builtin_amdgcn_s_memrealtime() >> p.phase_shift);
+            const unsigned ph = unsigned(realtime >> p.phase_shift);
             if (nbuf == kPhaseRows || (nbuf > 0 && ph != phase)) flush_outputs();
             phase = ph;
         }
