@@ -1,3 +1,5 @@
+"""Full-size check of the phased stores through a REUSED destination batch (zeroed before every run): every row of images 0 and n-1 against the oracle.
+How the lost-last-row bug of the first phased build was found (two rows completing with the last source row while the buffer held 7)."""
 import sys
 sys.path.insert(0, '.'); sys.path.insert(0, 'tests')
 import numpy as np, torch

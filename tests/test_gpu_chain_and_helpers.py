@@ -525,6 +525,8 @@ RUN_XCH_CASES = [
     ("rgba", (1000, 64), (250, 16), "mitchel", 1.0, (4, 15, 5)),
     ("rgba", (1536, 90), (512, 30), "cubic", 0.70, (3, 8, 2)),
     ("r16g16b16a16", (512, 1400), (128, 350), "mitchel", 1.0, (4, 15, 5)),    # tall: a phased buffer of 8 rows fills many times over
+    ("r16g16b16a16", (512, 228), (128, 57), "mitchel", 1.0, (4, 15, 5)),      # 57 rows in one chunk: rows 55 and 56 complete with the same (last) source row
+                                                                              # when the phase buffer holds 7 — the case that lost a row once
 ]
 
 
