@@ -8,7 +8,7 @@ mkdir -p build/var_$tag ../variants
 objs=""
 for n in 0 1 2 3 4 5 6 7; do
   if [[ " $pix " == *" $n "* ]]; then
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize -DPICHA_RUN_PIXEL=$n $flags -c kernels_run.hip -o build/var_$tag/run_p$n.o &
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -fno-slp-vectorize -mllvm -pragma-unroll-threshold=200000 -DPICHA_RUN_PIXEL=$n $flags -c kernels_run.hip -o build/var_$tag/run_p$n.o &
     objs="$objs build/var_$tag/run_p$n.o"
   else objs="$objs build/run_p$n.o"; fi
 done
