@@ -816,7 +816,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // Measured and not kept (profiles/r04_ab_run_ws.txt): both phases scalar (97 VGPRs, one short of a fifth wave per SIMD: +2 % exact, +12 % fma),
 // two row buffers instead of three (a tie), eight outputs per lane for the 30-tap shape (143 VGPRs once its 82-pixel window loop unrolls — see the
 // Makefile's -pragma-unroll-threshold; rolled, it indexed its registers dynamically and took 17 ms: -2.5 % exact at 12 chunks, +3 % fma).
-#define PICHA_RUNZ_LIST_0(Z) /* rgb */
+#define PICHA_RUNZ_LIST_0(Z) /* rgb */   /* 7.5x / 21 taps with two or four outputs per lane, scalar phase weights or not: -2 % exact, +7 % fma against resize_acc (r04, as r03 had found): not instantiated */
 #define PICHA_RUNZ_LIST_1(Z) /* rgba */ Z(1, 4, 11, 2, 0, 3, 0) Z(1, 4, 15, 2, 0, 5, 0) Z(1, 3, 8, 2, 0, 2, 0)
 #define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1)
 #define PICHA_RUNZ_LIST_3(Z) /* greya */ Z(2, 15, 30, 2, 1, -1, 1) Z(2, 15, 31, 2, 0, -1, 1)
