@@ -20,6 +20,5 @@ for t in cfg2 cfg2fma cfg5 cfg3 cfg3b cfg3a; do cp gpurun_out/prof_r04f_$t/summa
 python scripts/make_traffic.py $o/prof_cfg2_summary.txt $o/bench_line.json 4 > $o/traffic_cfg2.json 2> $o/traffic.err
 python scripts/make_traffic.py $o/prof_cfg2fma_summary.txt $o/bench_line_fma.json 4 > $o/traffic_cfg2_fma.json 2>> $o/traffic.err
 PICHA_HIP_LIB=picha_amd/variants/libpicha_hip_probe.so timeout -k 10 500 python scripts/r04_clock_probe.py > $o/clock.txt 2>&1
-PICHA_HIP_LIB=picha_amd/variants/libpicha_hip_probe2.so timeout -k 10 500 python scripts/r04_clock_probe.py > $o/clock_stream.txt 2>&1
 rocm-smi --showserial --showuniqueid > $o/device.txt 2>&1
-cat $o/bench_line.json | cut -c1-600; cat $o/bench_workloads.txt; grep -v amdgpu.ids $o/clock.txt | cut -c1-200; grep "cfg1\|7-tap" $o/clock_stream.txt | cut -c1-220
+cat $o/bench_line.json | cut -c1-600; cat $o/bench_workloads.txt; grep -v amdgpu.ids $o/clock.txt | cut -c1-200
