@@ -167,8 +167,8 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "run_round"  its window offsets inside a period: 0 = auto (the rounding with the shorter window), 1 = down, 2 = up
  *                ("run" = 3 is a measurement aid: the run kernel WITHOUT its edge columns — those come out wrong)
  *   "fuse"       picha_hip_convert_resize*: 0 = one fused kernel where it exists and was measured faster (default: every
- *                convert -> downscale pair of the row-staged kernel; resize -> convert for 16-bit and rgba sources), 1 = one
- *                kernel wherever an instantiation exists, 2 = always two kernels
+ *                convert -> downscale pair of the row-staged kernel; resize -> convert for 16-bit and rgba sources; r04: convert ->
+ *                integer upscale for the codec-edge pairs), 1 = one kernel wherever an instantiation exists, 2 = always two kernels
  *   "cc_mode"    colour convert layout: 0 = auto, 1 = the 4-pixel kernel, 2 = wide kernel with non-temporal
  *                stores, 3 = store-shaped kernel for expanding pairs
  *   "xcd_remap"  streaming kernels: 0 = auto, 1 = always / 2 = never permute workgroup ids so that each XCD works
@@ -192,7 +192,8 @@ long picha_hip_get_option(const char *key);
  *                            window; ",epilogue -> fmt": colour convert fused in at the store), "resize_acc_long<...>" (> 36 taps)
  *   "resize_rows<...>"       row-staged LDS kernel ("src chN -> chM": colour convert fused in)
  *   "resize_up<...> / resize_ring<...> + resize_edges<N columns>"   ring-in-registers kernel: 2x / 4x upscales (F: factor, P outputs
- *                            per lane) / ring-aliased lanczos downscales (K ring rows), and the edge-column kernel
+ *                            per lane) / ring-aliased lanczos downscales (K ring rows), and the edge-column kernel; "resize_up<src chNuM,...":
+ *                            (r04) a colour convert from that source format fused in front (picha_hip_convert_resize*, convert first)
  *   "resize_run<...> + resize_edges<N columns>"   run kernel (Q outputs / PX source pixels per period, P outputs per lane; r04: ",xchN" neighbour
  *                            exchange with N window pixels in front of the lane's own, ",wsN" N phases' weights in SGPRs, ",phasedM" time-phased
  *                            stores with phases of 2^M x 10 ns) and the kernel that recomputes the N columns whose windows an image edge clips

@@ -978,10 +978,13 @@ bool run_xch_preferred(int pixel, int period_px, int taps, int per_lane, int fma
 
 // Run kernel for one equal-geometry group: downscales whose x scale is a ratio of small integers with a long window.
 // *used = false: not applicable, the caller goes on with the other kernels.
-int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, int filter, float fscale, hipStream_t s, bool *used) {
+// cv != nullptr (r04): src[] are in another pixel format than dst[] — picha.colorConvert to dst[].pixel, then picha.resize, as ONE kernel: integer
+// upscales only (the convert runs per window pixel in the ring kernel, kernels_run.hip); the result is the two-call chain's, byte for byte.
+struct ChainConvert { float r, g, b; };
+int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, int n, int filter, float fscale, hipStream_t s, bool *used, const ChainConvert *cv = nullptr) {
     *used = false;
     const picha_image &s0 = src[0], &d0 = dst[0];
-    const int pixel = s0.pixel;
+    const int pixel = d0.pixel, spixel = s0.pixel;   // the format the kernel computes in / the format it loads
     long opt_run, opt_run_round, opt_numerics, opt_chunks, opt_per_lane, opt_work, opt_work_tail, opt_work_tail_div, opt_bw, opt_run_xch, opt_run_ws, opt_run_phase;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
@@ -991,14 +994,14 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
         opt_bw = g_opt_block_waves;
     }
-    if (opt_run == 2 || s0.pixel != d0.pixel) return PICHA_OK;
+    if (opt_run == 2 || ((s0.pixel != d0.pixel) != (cv != nullptr))) return PICHA_OK;
     // downscales (the march + per-source-row records), or upscales by an integer factor in x (resize_up_kernel: register ring in y)
     const bool up = d0.width > s0.width && d0.height > s0.height;
-    if (!up && (d0.width >= s0.width || d0.height >= s0.height)) return PICHA_OK;
+    if (!up && (cv || d0.width >= s0.width || d0.height >= s0.height)) return PICHA_OK;
     if (up && (d0.width % s0.width != 0 || d0.width / s0.width > 4)) return PICHA_OK;
     const size_t src_span = image_span(s0), dst_span = image_span(d0);
     if (src_span >= (1u << 30) || dst_span >= (1u << 30)) return PICHA_OK;
-    const int al = fused_align(pixel);
+    const int al = fused_align(spixel);
     for (int i = 0; i < n; ++i) {
         if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) return PICHA_OK;
         if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % 4) return PICHA_OK;  // a lane stores its run as whole dwords
@@ -1035,7 +1038,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
             const int t0 = run_table_taps(ax->host, period, period_px, c, &xb0);
             for (int tx = t0; t0 > 0 && tx <= t0 + 3 && !any; ++tx)
                 for (int pl : {2, 4, 8}) {
-                    if (up) { for (int k : {4}) any = any || up_kernel_supported(pixel, period, period_px, tx, pl, c, k, ay->host.taps); }
+                    if (cv) any = any || up_cv_kernel_supported(pixel, spixel, period, period_px, tx, pl, c, 4, ay->host.taps);
+                    else if (up) { for (int k : {4}) any = any || up_kernel_supported(pixel, period, period_px, tx, pl, c, k, ay->host.taps); }
                     else {
                         for (int na : {4, 6})
                             any = any || run_kernel_supported(pixel, period, period_px, tx, pl, na, c) || run_kernel_supported(pixel, period, period_px, tx, pl, na, c, -1, 1) ||
@@ -1099,7 +1103,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         for (int tx = tx_of[c]; tx <= tx_of[c] + 3 && !per_lane; ++tx)
             for (int pl0 : (up || (period == 2 && period_px == 3) ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
                 const int pl = opt_per_lane > 0 ? (int)opt_per_lane : pl0;   // "per_lane" names the run length outright
-                if (pl % period || !(ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : (run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c) || (opt_run_ws != 2 && run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c, -1, 1))))) continue;
+                if (pl % period || !(cv ? up_cv_kernel_supported(pixel, spixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : (run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c) || (opt_run_ws != 2 && run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c, -1, 1))))) continue;
                 per_lane = pl; ktaps = tx; ceil_off = c;
                 break;
             }
@@ -1126,7 +1130,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     const bool has_edges = rt->c0 > 0 || rt->c1 < d0.width;
     if (xhl >= 0 && rt->x_base != -xhl) return PICHA_OK;
     int stash_words = 0, stash_org[2] = {0, 0};
-    if (has_edges && xhl < 0) {
+    if (has_edges && xhl < 0 && !cv) {
         const int bpp = kBytes[pixel];
         const int span = ((per_lane - 1) / period) * period_px + (((per_lane - 1) % period) * period_px + ceil_off * (period - 1)) / period + ktaps;  // RunCfg::SPAN
         stash_words = bpp % 4 == 0 ? span * bpp / 4 : (span * bpp + 3) / 4 + 1;                                        // RunCfg::NW
@@ -1191,8 +1195,9 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         if (stash_used) r2 = temp_release(ctx->scratch, s);
         return r1 ? r1 : r2;
     };
-    if (has_edges && opt_run != 3 && xhl >= 0) p.edge_image = 1;
-    if (has_edges && opt_run != 3 && xhl < 0) {
+    if (has_edges && opt_run != 3 && (xhl >= 0 || cv)) p.edge_image = 1;
+    if (cv) { p.cv_on = 1; p.cv_src_pixel = spixel; p.cv_r = cv->r; p.cv_g = cv->g; p.cv_b = cv->b; }
+    if (has_edges && opt_run != 3 && xhl < 0 && !cv) {
         const size_t bytes = (size_t)n * 2 * s0.height * stash_words * 4;
         if (bytes >= ((size_t)1 << 32)) { (void)release_temps(); return PICHA_OK; }
         if (!temp_lock.owns_lock()) temp_lock.lock();
@@ -1306,6 +1311,17 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     }
     *used = true;
     return release_temps();
+}
+
+// where the one-kernel form of colorConvert -> integer upscale is the default (the instantiated pairs: kernels_run.hip, PICHA_UPCV_LIST; measured on
+// 256 x 960x540 / 512 x 480x270 -> 1080p, profiles/r04_ab_convert_up.txt): at 2x every pair, both flavours (-9 .. -29 % against convert + resize_up);
+// at 4x the launch is bound by its stores and the gain is smaller: -4 .. -18 % in the reference flavour except grey -> rgb (+-4 %), in the fma flavour
+// only the pairs below (grey -> rgb runs 40 % SLOWER there, rgba -> rgb and rgb -> rgba are ties).  "fuse" = 1 takes the one-kernel form wherever it exists.
+bool convert_up_preferred(int src_pixel, int dst_pixel, int factor, bool fma) {
+    if (factor <= 2) return true;
+    if (src_pixel == PICHA_GREY && dst_pixel == PICHA_RGB) return false;
+    if (!fma) return true;
+    return dst_pixel == PICHA_GREY || (src_pixel == PICHA_GREYA && dst_pixel == PICHA_RGBA);
 }
 
 // Row-staged kernel for one equal-geometry group (kernels_rows.hip): plain downscale (src.pixel == dst.pixel) or colour
@@ -2541,13 +2557,19 @@ int picha_hip_convert_resize_device(int n, const picha_image *src, const picha_i
         } else if ([&] {  // colour convert fused into the row-staged resize: the intermediate never exists in HBM
                        bool used = false;
                        rc = PICHA_OK;
-                       long fuse, path;
-                       { std::lock_guard<std::mutex> lk(g_opt_mu); fuse = g_opt_fuse; path = g_opt_path; }
+                       long fuse, path, numerics;
+                       { std::lock_guard<std::mutex> lk(g_opt_mu); fuse = g_opt_fuse; path = g_opt_path; numerics = tl_numerics >= 0 ? tl_numerics : g_opt_numerics; }
                        // like resize_group: a forced kernel family ("path" 1..4) is honoured, 5 means this kernel or an error
                        if (order == PICHA_CONVERT_THEN_RESIZE && fuse != 2 && (path == 0 || path == 5)) {
                            rc = rows_group(ctx, src + i, dst + i, j - i, filter, filter_scale, r, g, b, s, &used);
                            if (rc == PICHA_OK && !used && path == 5)
                                rc = fail(PICHA_ERR_ARGUMENT, "row-staged kernel forced but unsupported for this chain");
+                       }
+                       // colorConvert -> integer upscale (r04): the convert per window pixel inside the ring kernel
+                       if (order == PICHA_CONVERT_THEN_RESIZE && fuse != 2 && path == 0 && rc == PICHA_OK && !used &&
+                           (fuse == 1 || (s0.width > 0 && convert_up_preferred(s0.pixel, d0.pixel, d0.width / s0.width, numerics == 1)))) {
+                           const ChainConvert cv{r, g, b};
+                           rc = run_group(ctx, src + i, dst + i, j - i, filter, filter_scale, s, &used, &cv);
                        }
                        // resize -> colorConvert: the convert as a store epilogue of the accumulator kernel (r03), where the
                        // intermediate image would be large (downscales by up to ~4x: tap buckets 5 .. 16)

@@ -282,6 +282,11 @@ struct RunParams {
     int wsgpr;       // phases of the period whose weights stay in SGPRs (0 .. period)
     int edge_image;  // 1: resize_edges_kernel reads the edge columns' windows from the image, not from a stash
     int phase_shift; // > 0 (neighbour-exchange shapes): time-phased stores — finished rows wait in registers until s_memrealtime >> phase_shift changes
+    // colour convert in front of an integer upscale (r04, resize_ring_kernel / resize_edges_kernel): the source images are in cv_src_pixel, every window
+    // pixel goes through src/colorconvert.cc:136-152 (unpack, channel map, pack = the intermediate image's quantised samples) in registers and is then
+    // unpacked as the kernel's own format; no stash (edge_image = 1)
+    int cv_on, cv_src_pixel;
+    float cv_r, cv_g, cv_b;
 };
 bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc, int off_ceil, int xhl = -1, int wsgpr = 0);
 hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s, const char **kernel_name);
@@ -289,6 +294,7 @@ hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s
 // reference's): yrow_rec unused; yrow_range: per output row {first source row needed by it or any later row, last row so far}
 bool up_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int off_ceil, int ring_rows, int y_taps);
 hipError_t launch_resize_up_kernel(int pixel, const RunParams &p, hipStream_t s, const char **kernel_name);
+bool up_cv_kernel_supported(int pixel, int src_pixel, int period, int period_px, int taps, int per_lane, int off_ceil, int ring_rows, int y_taps);  // p.cv_on forms
 hipError_t launch_resize_edges_kernel(int pixel, const RunParams &p, hipStream_t s);  // after the run kernel, same stream: the columns outside [cx0, cx1)
 int run_kernel_resident_blocks(int pixel, const RunParams &p);
 

@@ -37,6 +37,7 @@ PICHA_DECL_SYM(4) PICHA_DECL_SYM(5) PICHA_DECL_SYM(6) PICHA_DECL_SYM(7)
     hipError_t launch_run_pixel##N(const RunParams &p, hipStream_t s, const char **name); \
     hipError_t launch_edges_pixel##N(const RunParams &p, hipStream_t s); \
     bool up_supported_pixel##N(int q, int px, int tx, int per_lane, int rc, int ring, int ty); \
+    bool up_cv_supported_pixel##N(int src_pixel, int q, int px, int tx, int per_lane, int rc, int ring, int ty); \
     hipError_t launch_up_pixel##N(const RunParams &p, hipStream_t s, const char **name);
 PICHA_DECL_RUN(0) PICHA_DECL_RUN(1) PICHA_DECL_RUN(2) PICHA_DECL_RUN(3)
 PICHA_DECL_RUN(4) PICHA_DECL_RUN(5) PICHA_DECL_RUN(6) PICHA_DECL_RUN(7)
@@ -60,6 +61,14 @@ hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s
 bool up_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int off_ceil, int ring_rows, int y_taps) {
     switch (pixel) {
 #define PICHA_CASE(N) case N: return up_supported_pixel##N(period, period_px, taps, per_lane, off_ceil, ring_rows, y_taps);
+    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
+#undef PICHA_CASE
+    }
+    return false;
+}
+bool up_cv_kernel_supported(int pixel, int src_pixel, int period, int period_px, int taps, int per_lane, int off_ceil, int ring_rows, int y_taps) {
+    switch (pixel) {
+#define PICHA_CASE(N) case N: return up_cv_supported_pixel##N(src_pixel, period, period_px, taps, per_lane, off_ceil, ring_rows, y_taps);
     PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
 #undef PICHA_CASE
     }

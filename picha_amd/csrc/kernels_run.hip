@@ -64,6 +64,56 @@ template <int CH, bool S16, int TXE> struct EdgeCfg {
     static constexpr int NW = WORDS ? SPAN * BPP / 4 : NWIN + 1;
 };
 
+// Colour convert in front of the resize (r04; convert -> upscale as ONE kernel): span pixel q of a window loaded in the SOURCE format Cs goes
+// through the reference's per-pixel convert (src/colorconvert.cc:136-152: unpack, ChannelConvertOp by channel count, pack) — its result is the
+// intermediate image's QUANTISED sample, which is what picha.resize would then read — and comes out unpacked the way the kernel's own format
+// CH / S16 unpacks (unpack_span_px: plain integer for fma, value x 1/max, or the 2^-22-scaled denormal form).  Pairs of equal sample depth that
+// only move samples around (no luma) skip the float round trip: pack(unpack(s)) == s for every sample, pack(1.0f) == max, pack(0.0f) == 0.
+template <typename Cs, int SCH, bool SS16, int CH, bool S16, bool FMA>
+__device__ __forceinline__ void convert_span_px(const uint32_t *raw, int q, float *u, float r, float g, float b) {
+    uint32_t sv[SCH];
+#pragma unroll
+    for (int c = 0; c < SCH; ++c) {
+        const int bpos = q * Cs::BPP + c * Cs::BPS;   // byte position inside the span: a constant after unrolling
+        sv[c] = (raw[bpos / 4] >> (8 * (bpos % 4))) & (SS16 ? 0xffffu : 0xffu);
+    }
+    uint32_t dv[CH];
+    constexpr bool kLuma = SCH >= 3 && CH <= 2;
+    if constexpr (SS16 == S16 && !kLuma) {
+        constexpr uint32_t kOne = S16 ? 65535u : 255u;
+        if constexpr (SCH == CH) {
+#pragma unroll
+            for (int c = 0; c < CH; ++c) dv[c] = sv[c];
+        } else if constexpr (SCH == 1) {
+            dv[0] = sv[0];
+            if constexpr (CH == 2) dv[1] = kOne;
+            if constexpr (CH >= 3) { dv[1] = sv[0]; dv[2] = sv[0]; }
+            if constexpr (CH == 4) dv[3] = kOne;
+        } else if constexpr (SCH == 2) {
+            dv[0] = sv[0];
+            if constexpr (CH == 1) { }
+            if constexpr (CH == 3) { dv[1] = sv[1]; dv[2] = 0u; }
+            if constexpr (CH == 4) { dv[1] = sv[0]; dv[2] = sv[0]; dv[3] = sv[1]; }
+        } else {  // 3 -> 4 or 4 -> 3
+            dv[0] = sv[0]; dv[1] = sv[1]; dv[2] = sv[2];
+            if constexpr (CH == 4) dv[3] = kOne;
+        }
+    } else {
+        float fs[SCH], fd[CH];
+#pragma unroll
+        for (int c = 0; c < SCH; ++c) fs[c] = unpack_sample<SS16>(sv[c]);
+        channel_map<SCH, CH>(fs, fd, r, g, b);
+#pragma unroll
+        for (int c = 0; c < CH; ++c) dv[c] = pack_sample<S16>(fd[c]);
+    }
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+        if constexpr (FMA) u[c] = float(dv[c]);
+        else if constexpr (exact_unpack_scaled(CH, S16)) u[c] = mul_denorm_bits<6>(dv[c], Sample<S16>::kDen);
+        else u[c] = unpack_sample<S16>(dv[c]);
+    }
+}
+
 // Edge columns [xa0, xa0 + na) of one side of one image for the output rows [y0, y1), by one wave; the reference's double sum
 // (src/resize.cc:110-117 into a zeroed row, :125-129 over the rows the ring holds for the window's taps: y_eff) with the columns' own weights from the generic tables, reference arithmetic in
 // both numerics flavours.  The source pixels come from the STASH the march wrote: per (image, side, source row) the NRAW raw
@@ -76,10 +126,13 @@ template <int CH, bool S16, int TXE> struct EdgeCfg {
 // the march already paid (141-283 MB for cfg3b: 0.03-0.07 ms, alone or as an epilogue of the march's waves, whatever the form
 // of the loop — r03, profiles/r03_ab_run_kernel.txt); the march has those bytes in registers.
 constexpr int kEdgeFloats = 2048;
-template <int CH, bool S16, int TXE>
+template <int CH, bool S16, int TXE, int SRCP = -1>
 __device__ __forceinline__ void edge_pass(const RunParams &p, __amdgpu_buffer_rsrc_t stash_rs, int st_stride, int st_org, __amdgpu_buffer_rsrc_t dst_rs,
                                           int lane, float *lds, int xa0, int na, int y0, int y1) {
-    using E = EdgeCfg<CH, S16, TXE>;
+    constexpr int SCH = SRCP < 0 ? CH : pixel_channels(SRCP < 0 ? 0 : SRCP);
+    constexpr bool SS16 = SRCP < 0 ? S16 : pixel_is16(SRCP < 0 ? 0 : SRCP);
+    using E = EdgeCfg<SCH, SS16, TXE>;   // the windows as they are loaded (SRCP >= 0: the source format of a convert in front)
+    using ED = EdgeCfg<CH, S16, TXE>;
     constexpr bool SC = exact_unpack_scaled(CH, S16);  // such formats unpack through the denormal form: weights times 2^22 (exact)
     const_i32_ptr xl = (const_i32_ptr)(p.x_left);
     const_i32_ptr yrange = (const_i32_ptr)(p.yrow_range);
@@ -128,7 +181,8 @@ __device__ __forceinline__ void edge_pass(const RunParams &p, __amdgpu_buffer_rs
 #pragma unroll
                         for (int t = 0; t < TXE; ++t) {
                             float u[CH];
-                            if constexpr (E::BROT) unpack_span_px<E, CH, S16, false>(win, t, u);
+                            if constexpr (SRCP >= 0) convert_span_px<E, SCH, SS16, CH, S16, false>(E::BROT ? win : raw[g], t, u, p.cv_r, p.cv_g, p.cv_b);
+                            else if constexpr (E::BROT) unpack_span_px<E, CH, S16, false>(win, t, u);
                             else unpack_span_px<E, CH, S16, false>(raw[g], t, u);
                             const float w = lds_wx[c * TXE + t];  // every lane the same address
 #pragma unroll
@@ -164,7 +218,7 @@ __device__ __forceinline__ void edge_pass(const RunParams &p, __amdgpu_buffer_rs
             if (ya + lane < yb) {
                 uint32_t pw[2];
                 pack_px_words<CH, S16, false>(acc, pw);
-                store_px_words<CH, S16>(dst_rs, uint32_t(yl * p.dst_stride + x * E::BPP), pw);
+                store_px_words<CH, S16>(dst_rs, uint32_t(yl * p.dst_stride + x * ED::BPP), pw);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -175,7 +229,7 @@ __device__ __forceinline__ void edge_pass(const RunParams &p, __amdgpu_buffer_rs
 // One wave per (block of p.edge_rows output rows, side of the image, image): launched after the march on the same stream, it
 // overwrites what the march stored in those columns with the canonical weights.  (As an epilogue of the march's waves the pass
 // cost 25 VGPRs on top of the march's and 5-12 % of its time.)
-template <int CH, bool S16, int TXE>
+template <int CH, bool S16, int TXE, int SRCP = -1>
 __global__ __launch_bounds__(64) void resize_edges_kernel(RunParams p) {
     extern __shared__ __attribute__((aligned(16))) float edge_lds[];
     const int lane = threadIdx.x;
@@ -192,9 +246,10 @@ __global__ __launch_bounds__(64) void resize_edges_kernel(RunParams p) {
         const uint8_t *sbase = uniform_ptr(p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch);
         const int sadj = int(reinterpret_cast<uintptr_t>(sbase) & 3u);
         const __amdgpu_buffer_rsrc_t img_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(sbase) - sadj, 0, (p.src_bytes + sadj + 3u) & ~3u, 0x00020000);
-        edge_pass<CH, S16, TXE>(p, img_rs, p.src_stride, -sadj, dst_rs, lane, edge_lds, xa0, na, y0, y1);
+        edge_pass<CH, S16, TXE, SRCP>(p, img_rs, p.src_stride, -sadj, dst_rs, lane, edge_lds, xa0, na, y0, y1);
         return;
     }
+    if constexpr (SRCP >= 0) return;   // (a convert in front always reads the image)
     const unsigned st_stride = unsigned(p.stash_words) * 4u, st_bytes = st_stride * unsigned(p.src_h);
     const __amdgpu_buffer_rsrc_t stash_rs = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<uint8_t *>(p.stash) + (size_t)((p.stash_img0 + img) * 2 + side) * st_bytes, 0, st_bytes, 0x00020000);
@@ -568,12 +623,18 @@ template <int N, int I = 0, typename Fn> __device__ __forceinline__ void unroll_
 //     itself, as in the LDS-ring kernel, without its LDS traffic and per-tap slot loads.
 // Edge columns as for the run kernel: stash + resize_edges_kernel.
 // ---------------------------------------------------------------------------------------------
-template <int CH, bool S16, int Q, int PX, int TX, int P, int K, int TYM, bool FMA, int RC>
+//   * SRCP >= 0 (r04): a colour convert in front (picha.colorConvert, then picha.resize, as ONE kernel): the windows are loaded in the source
+//     format SRCP and every window pixel is converted and quantised in registers (convert_span_px) before it meets its weights; the clipped
+//     columns are recomputed from the image by resize_edges_kernel<..., SRCP> (no stash).
+template <int CH, bool S16, int Q, int PX, int TX, int P, int K, int TYM, bool FMA, int RC, int SRCP = -1>
 __global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
     using C = RunCfg<CH, S16, Q, PX, TX, P, RC>;
+    constexpr int SCH = SRCP < 0 ? CH : pixel_channels(SRCP < 0 ? 0 : SRCP);
+    constexpr bool SS16 = SRCP < 0 ? S16 : pixel_is16(SRCP < 0 ? 0 : SRCP);
+    using CS = RunCfg<SCH, SS16, Q, PX, TX, P, RC>;   // the windows as they are loaded
     constexpr int F = Q;
     static_assert(P % F == 0, "a lane owns whole periods");
-    constexpr int NRAW = C::NW;
+    constexpr int NRAW = CS::NW;
     constexpr int NB = 4;  // row buffers; K is a multiple of it: one unrolled group of K rows
     PICHA_PROBE_BEGIN
     const int lane = threadIdx.x & (kWave - 1);
@@ -587,9 +648,9 @@ __global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
 
     const uint8_t *sbase = uniform_ptr(p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch);
     uint8_t *dbase = uniform_ptr(p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch);
-    const int sadj = C::BROT ? int(reinterpret_cast<uintptr_t>(sbase) & 3u) : 0;
+    const int sadj = CS::BROT ? int(reinterpret_cast<uintptr_t>(sbase) & 3u) : 0;
     const __amdgpu_buffer_rsrc_t src_rs = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint8_t *>(sbase) - sadj, 0, C::WORDS ? p.src_bytes : ((p.src_bytes + sadj + 3u) & ~3u), 0x00020000);
+        const_cast<uint8_t *>(sbase) - sadj, 0, CS::WORDS ? p.src_bytes : ((p.src_bytes + sadj + 3u) & ~3u), 0x00020000);
     const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
 
     const_i32_ptr xc = (const_i32_ptr)(p.x_canon);
@@ -602,7 +663,7 @@ __global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
 #pragma unroll
         for (int j = 0; j < TX; ++j) asm("v_mov_b32 %0, %1" : "=v"(wx[q][j]) : "s"(wbits[q * TX + j]));
     static_assert(K % NB == 0 && TYM <= K + 1, "ring");
-    const int32_t lane_off = (p.x_base + (grp0 + lane) * ((P / F) * PX)) * C::BPP + sadj;
+    const int32_t lane_off = (p.x_base + (grp0 + lane) * ((P / F) * PX)) * CS::BPP + sadj;
     const bool careful = __any(lane_off < 0);
 
     const_i32_ptr yrange = (const_i32_ptr)(p.yrow_range);
@@ -652,8 +713,8 @@ __global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
     for (int k = 0; k < NB - 1; ++k) {
         const int row = min(r0 + k, r1);
         const int32_t off = row * p.src_stride + lane_off;
-        if (careful && row <= 0) load_span<C, true>(src_rs, off, raw[k]);
-        else load_span<C, false>(src_rs, off, raw[k]);
+        if (careful && row <= 0) load_span<CS, true>(src_rs, off, raw[k]);
+        else load_span<CS, false>(src_rs, off, raw[k]);
     }
 
     float ring[K][P][CH];   // resampled rows, slot = (row - r0) mod K
@@ -702,13 +763,14 @@ __global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
         constexpr int SL = decltype(slot_c)::value;   // == (row - r0) mod K
         if (st_wave && row <= r1) stash_row(cur, row);
         // ---- horizontal pass (src/resize.cc:110-117) ----
-        uint32_t win[C::BROT ? C::NWIN : 1];
-        if constexpr (C::BROT) rotate_span<C>(cur, uint32_t(min(row, r1) * p.src_stride + lane_off) & 3u, win);
+        uint32_t win[CS::BROT ? CS::NWIN : 1];
+        if constexpr (CS::BROT) rotate_span<CS>(cur, uint32_t(min(row, r1) * p.src_stride + lane_off) & 3u, win);
         float h[P][CH];
 #pragma unroll
         for (int q = 0; q < C::SPAN; ++q) {
             float u[CH];
-            if constexpr (C::BROT) unpack_span_px<C, CH, S16, FMA>(win, q, u);
+            if constexpr (SRCP >= 0) convert_span_px<CS, SCH, SS16, CH, S16, FMA>(CS::BROT ? win : cur, q, u, p.cv_r, p.cv_g, p.cv_b);
+            else if constexpr (C::BROT) unpack_span_px<C, CH, S16, FMA>(win, q, u);
             else unpack_span_px<C, CH, S16, FMA>(cur, q, u);
 #pragma unroll
             for (int o = 0; o < P; ++o) {
@@ -741,22 +803,25 @@ __global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
     // The unrolled group starts at r0, so position k of a group is ring slot (row - r0) mod K
     auto step = [&](int r, auto k_c) __attribute__((always_inline)) {
         constexpr int KK = decltype(k_c)::value;
-        load_span<C, false>(src_rs, max(1, min(r + KK + NB - 1, r1)) * p.src_stride + lane_off, raw[(KK + NB - 1) % NB]);
+        load_span<CS, false>(src_rs, max(1, min(r + KK + NB - 1, r1)) * p.src_stride + lane_off, raw[(KK + NB - 1) % NB]);
         if (r + KK <= r1) process_row(raw[KK % NB], r + KK, k_c);
     };
     for (int r = r0; r <= r1; r += K) unroll_steps<K>(r, step);
     PICHA_PROBE_END
 }
 
-template <int CH, bool S16, int Q, int PX, int TX, int P, int RC, int K, int TYM>
+template <int CH, bool S16, int Q, int PX, int TX, int P, int RC, int K, int TYM, int SRCP = -1>
 hipError_t launch_ring_t(const RunParams &p, hipStream_t s, const char **name) {
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 4;
     const size_t lds = p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, Q, PX, TX, P, RC>::NW + 3) / 4 * 4) : 0;
+    if (SRCP >= 0 && p.stash) return hipErrorInvalidValue;   // a convert in front: the edge columns come from the image
     dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
-    if (p.fma) resize_ring_kernel<CH, S16, Q, PX, TX, P, K, TYM, true, RC><<<grid, 64 * bw, lds, s>>>(p);
-    else resize_ring_kernel<CH, S16, Q, PX, TX, P, K, TYM, false, RC><<<grid, 64 * bw, lds, s>>>(p);
-    if (Q > PX) snprintf(g_kernel_name, sizeof g_kernel_name, "resize_up<ch%d,%s,F%d,TX%d,P%d,%s,bw%d%s>", CH, S16 ? "u16" : "u8", Q, TX, P, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "");
-    else snprintf(g_kernel_name, sizeof g_kernel_name, "resize_ring<ch%d,%s,Q%d,PX%d,TX%d,P%d,K%d,%s,bw%d%s>", CH, S16 ? "u16" : "u8", Q, PX, TX, P, K, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "");
+    if (p.fma) resize_ring_kernel<CH, S16, Q, PX, TX, P, K, TYM, true, RC, SRCP><<<grid, 64 * bw, lds, s>>>(p);
+    else resize_ring_kernel<CH, S16, Q, PX, TX, P, K, TYM, false, RC, SRCP><<<grid, 64 * bw, lds, s>>>(p);
+    char srcs[24] = "";
+    if (SRCP >= 0) snprintf(srcs, sizeof srcs, "src ch%d%s,", pixel_channels(SRCP < 0 ? 0 : SRCP), pixel_is16(SRCP < 0 ? 0 : SRCP) ? "u16" : "u8");
+    if (Q > PX) snprintf(g_kernel_name, sizeof g_kernel_name, "resize_up<%sch%d,%s,F%d,TX%d,P%d,%s,bw%d%s>", srcs, CH, S16 ? "u16" : "u8", Q, TX, P, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "");
+    else snprintf(g_kernel_name, sizeof g_kernel_name, "resize_ring<%sch%d,%s,Q%d,PX%d,TX%d,P%d,K%d,%s,bw%d%s>", srcs, CH, S16 ? "u16" : "u8", Q, PX, TX, P, K, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "");
     if (name) *name = g_kernel_name;
     return hipGetLastError();
 }
@@ -838,6 +903,20 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #define PICHA_UP_LIST_6(U) /* r16g16b16 */ U(1, 2, 9, 2, 0, 8, 9) U(2, 1, 3, 2, 1, 4, 4) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 2, 0, 4, 4)
 #define PICHA_UP_LIST_7(U) /* r16g16b16a16 */ U(1, 2, 9, 2, 0, 8, 9)   /* upscales: four outputs per lane measured 13 % slower than the accumulator form (0.49 against 0.56) */
 
+// Convert-in-front instantiations of the ring kernel (r04): V(SRCP, Q, PX, TX, P, RC, K, TYM) under the DESTINATION format's translation unit — the codec-edge
+// pairs of DESIGN.md 6.3 (-> jpeg: rgb / grey; -> webp: rgb / rgba; deep png -> 8 bit) at 2x with picha's defaults (3 taps, offsets rounded up) and at 4x.
+#define PICHA_UPCV_LIST_0(V) /* -> rgb */ V(1, 2, 1, 3, 4, 1, 4, 4) V(2, 2, 1, 3, 4, 1, 4, 4) V(6, 2, 1, 3, 4, 1, 4, 4) V(7, 2, 1, 3, 4, 1, 4, 4) \
+    V(1, 4, 1, 4, 8, 0, 4, 4) V(2, 4, 1, 4, 8, 0, 4, 4)
+#define PICHA_UPCV_LIST_1(V) /* -> rgba */ V(0, 2, 1, 3, 4, 1, 4, 4) V(3, 2, 1, 3, 4, 1, 4, 4) V(7, 2, 1, 3, 4, 1, 4, 4) \
+    V(0, 4, 1, 4, 8, 0, 4, 4) V(3, 4, 1, 4, 8, 0, 4, 4)
+#define PICHA_UPCV_LIST_2(V) /* -> grey */ V(0, 2, 1, 3, 8, 1, 4, 4) V(1, 2, 1, 3, 8, 1, 4, 4) V(3, 2, 1, 3, 8, 1, 4, 4) V(4, 2, 1, 3, 8, 1, 4, 4) \
+    V(0, 4, 1, 4, 8, 0, 4, 4) V(1, 4, 1, 4, 8, 0, 4, 4)
+#define PICHA_UPCV_LIST_3(V)
+#define PICHA_UPCV_LIST_4(V)
+#define PICHA_UPCV_LIST_5(V)
+#define PICHA_UPCV_LIST_6(V)
+#define PICHA_UPCV_LIST_7(V)
+
 }  // namespace
 
 #ifndef PICHA_RUN_PIXEL
@@ -847,6 +926,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #define PICHA_RUN_LIST_X(X)
 #define PICHA_UP_LIST_X(U)
 #define PICHA_RUNZ_LIST_X(Z) PICHA_RUN_EXPERIMENT
+#define PICHA_UPCV_LIST_X(V)
 #undef PICHA_RUN_PIXEL_LISTS
 #define PICHA_RUN_PIXEL_LISTS X
 #else
@@ -857,6 +937,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #define PICHA_RUN_LIST PICHA_CAT(PICHA_RUN_LIST_, PICHA_RUN_PIXEL_LISTS)
 #define PICHA_RUNZ_LIST PICHA_CAT(PICHA_RUNZ_LIST_, PICHA_RUN_PIXEL_LISTS)
 #define PICHA_UP_LIST PICHA_CAT(PICHA_UP_LIST_, PICHA_RUN_PIXEL_LISTS)
+#define PICHA_UPCV_LIST PICHA_CAT(PICHA_UPCV_LIST_, PICHA_RUN_PIXEL_LISTS)
 
 PICHA_PROBE_HOST(PICHA_CAT(picha_probe_run_p, PICHA_RUN_PIXEL))
 
@@ -903,9 +984,22 @@ bool PICHA_CAT(up_supported_pixel, PICHA_RUN_PIXEL)(int q, int px, int tx, int p
     return false;
 }
 
+bool PICHA_CAT(up_cv_supported_pixel, PICHA_RUN_PIXEL)(int src_pixel, int q, int px, int tx, int per_lane, int rc, int ring, int ty) {
+#define V(SRCP, Q, PX, TX, P, RC, K, TYM) if (src_pixel == SRCP && q == Q && px == PX && tx == TX && per_lane == P && rc == RC && ring == K && ty <= TYM) return true;
+    PICHA_UPCV_LIST(V)
+#undef V
+    return false;
+}
+
 hipError_t PICHA_CAT(launch_up_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipStream_t s, const char **name) {
     [[maybe_unused]] constexpr int CH = pixel_channels(PICHA_RUN_PIXEL);
     [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
+    if (p.cv_on) {
+#define V(SRCP, Q, PX, TX, P, RC, K, TYM) if (p.cv_src_pixel == SRCP && p.period == Q && p.period_px == PX && p.x_taps == TX && p.x_per_lane == P && p.off_ceil == RC && p.ring_rows == K) return launch_ring_t<CH, S16, Q, PX, TX, P, RC, K, TYM, SRCP>(p, s, name);
+        PICHA_UPCV_LIST(V)
+#undef V
+        return hipErrorInvalidValue;
+    }
 #define U(Q, PX, TX, P, RC, K, TYM) if (p.period == Q && p.period_px == PX && p.x_taps == TX && p.x_per_lane == P && p.off_ceil == RC && p.ring_rows == K) return launch_ring_t<CH, S16, Q, PX, TX, P, RC, K, TYM>(p, s, name);
     PICHA_UP_LIST(U)
 #undef U
@@ -919,6 +1013,13 @@ hipError_t PICHA_CAT(launch_edges_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hi
     [[maybe_unused]] dim3 grid((p.dst_h + p.edge_rows - 1) / p.edge_rows, 2, p.n_images);
     [[maybe_unused]] const size_t lds = sizeof(float) * kEdgeFloats;
     [[maybe_unused]] const int txe = (p.x_taps + 3) / 4 * 4;
+    if (p.cv_on) {
+        if (!p.edge_image) return hipErrorInvalidValue;
+#define V(SRCP, Q, PX, TX, P, RC, K, TYM) if (p.cv_src_pixel == SRCP && txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4, SRCP><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
+        PICHA_UPCV_LIST(V)
+#undef V
+        return hipErrorInvalidValue;
+    }
 #define X(Q, PX, TX, P, RC) if (txe == (TX + 3) / 4 * 4) { resize_edges_kernel<CH, S16, (TX + 3) / 4 * 4><<<grid, 64, lds, s>>>(p); return hipGetLastError(); }
     PICHA_RUN_LIST(X)
 #undef X

@@ -135,7 +135,7 @@ def test_reference_arithmetic_kernels_have_no_fused_multiply_add(device_disassem
             re.search(r"resize_sym_kernelI.*ELb([01])ELb[01]ELb[01]EEEvNS_", name) or \
             re.search(r"resize_rows_kernelI.*ELb([01])EEEvNS_", name) or \
             re.search(r"resize_run_kernelI.*ELb([01])ELi[01]ELin?\d+ELi\d+ELi[01]EEEvNS_", name) or \
-            re.search(r"resize_ring_kernelI.*ELb([01])ELi[01]EEEvNS_", name)  # run: <..., FMA, RC, XHL, WS, PH>, ring: <..., FMA, RC>; resize_edges_kernel is reference arithmetic only
+            re.search(r"resize_ring_kernelI.*ELb([01])ELi[01]ELin?\d+EEEvNS_", name)  # run: <..., FMA, RC, XHL, WS, PH>, ring: <..., FMA, RC, SRCP>; resize_edges_kernel is reference arithmetic only
         if m and m.group(1) == "1":
             fma_flavour += 1
             assert body["fused"], "fma flavour without fma? " + name

@@ -674,3 +674,55 @@ def test_resize_then_convert_epilogue_on_the_symmetric_table_kernel(case):
     finally:
         for k in keys:
             N.check(N.lib().picha_hip_set_option(k, 0))
+
+
+CONVERT_UP_PAIRS = [   # (source, destination): the codec-edge pairs instantiated in kernels_run.hip (PICHA_UPCV_LIST)
+    ("rgba", "rgb"), ("grey", "rgb"), ("r16g16b16", "rgb"), ("r16g16b16a16", "rgb"),
+    ("rgb", "rgba"), ("greya", "rgba"), ("r16g16b16a16", "rgba"),
+    ("rgb", "grey"), ("rgba", "grey"), ("greya", "grey"), ("r16", "grey"),
+]
+
+
+@pytest.mark.parametrize("pair", CONVERT_UP_PAIRS, ids=lambda c: "%s-%s" % c)
+def test_convert_then_integer_upscale_as_one_kernel_equals_two_reference_calls(pair):
+    """r04: colorConvert -> integer upscale as ONE kernel — resize_up with the convert per window pixel, the intermediate
+    image's samples quantised in registers (src/colorconvert.cc:136-152, then src/resize.cc:99-132) — against oracle colorConvert -> oracle
+    resize, bit for bit (fma <= 1), and byte-equal to the two-kernel chain: 2x and 4x in x, several vertical factors, padded strides, edge
+    values, default and custom luma weights, row chunkings; geometries without an instantiation fall back to the chain."""
+    sp, dp = pair
+    rng = np.random.default_rng(7100 + CONVERT_UP_PAIRS.index(pair))
+    served = 0
+    keys = (b"fuse", b"row_chunks", b"numerics")
+    geoms = [(96, 40, 192, 80, None, 0.70), (161, 30, 322, 75, None, 0.70), (130, 33, 260, 103, None, 0.70),
+             (300, 21, 600, 42, None, 0.70), (80, 30, 320, 120, None, 0.70), (73, 25, 292, 77, None, 0.70),
+             (96, 40, 192, 80, "mitchel", 1.0)]    # (4-tap filters at 2x: not instantiated with a convert in front -> the chain)
+    try:
+        for (sw, sh, dw, dh, filt, fscale) in geoms:
+            img = rand_image(rng, sw, sh, sp, pad=int(rng.choice([0, 8])), edge_values=bool(rng.integers(0, 3) == 0))
+            for weights in (None, (0.2, 0.5, 0.3)):
+                cs = picha.color_settings(*weights) if weights else None
+                want = oracle_resize(oracle_convert(img, dp, cs), dw, dh, filt or "cubic", fscale)
+                opts = {"pixel": dp, "width": dw, "height": dh, "filterScale": fscale, "order": "convertFirst"}
+                if filt: opts["filter"] = filt
+                if weights: opts.update(redWeight=weights[0], greenWeight=weights[1], blueWeight=weights[2])
+                for fuse, chunks in ((1, 0), (1, 3), (0, 0), (2, 0)):
+                    N.check(N.lib().picha_hip_set_option(b"fuse", fuse))
+                    N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
+                    got = picha.convertResizeSync(img, opts)
+                    name = N.lib().picha_hip_last_kernel().decode()
+                    one = name.startswith("resize_up<src ")
+                    served += one and fuse == 1 and chunks == 0
+                    assert not (fuse == 2 and one), name
+                    assert (got.width, got.height, got.pixel) == (dw, dh, dp)
+                    assert np.array_equal(payload(got), payload(want)), (pair, sw, sh, dw, dh, filt, weights, fuse, chunks, name, max_code_diff(got, want))
+                N.check(N.lib().picha_hip_set_option(b"fuse", 1))
+                N.check(N.lib().picha_hip_set_option(b"row_chunks", 0))
+                N.check(N.lib().picha_hip_set_option(b"numerics", 1))
+                got = picha.convertResizeSync(img, opts)
+                assert max_code_diff(got, want) <= 1, (pair, sw, filt, "fma", N.lib().picha_hip_last_kernel())
+                N.check(N.lib().picha_hip_set_option(b"numerics", 0))
+    finally:
+        for k in keys:
+            N.check(N.lib().picha_hip_set_option(k, 0))
+    four_x = (sp, dp) in (("rgba", "rgb"), ("grey", "rgb"), ("rgb", "rgba"), ("greya", "rgba"), ("rgb", "grey"), ("rgba", "grey"))
+    assert served >= (12 if four_x else 8), served

@@ -17,7 +17,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up", "run", "run_round", "run_xch", "run_ws", "run_phase"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up", "run", "run_round", "run_xch", "run_ws", "run_phase", "fuse"):
         set_opt(k, 0)
 
 
@@ -198,8 +198,11 @@ def test_random_device_batches_match_oracle(seed):
     bpp = N.PIXEL_BYTES[pixel]
     geoms = []
     for _ in range(int(rng.integers(1, 3))):
-        f = int(rng.choice([2, 2, 3, 4, 0]))
-        if f:
+        f = int(rng.choice([2, 2, 3, 4, 0, -2, -4]))
+        if f < 0:   # integer upscales (resize_up; with a convert in front: its one-kernel form)
+            sw, sh = int(rng.integers(4, 120)), int(rng.integers(4, 40))
+            geoms.append((sw, sh, sw * -f, int(sh * rng.choice([2, 2.5, 3, 4]))))
+        elif f:
             dw, dh = int(rng.integers(4, 200)), int(rng.integers(4, 70))
             geoms.append((dw * f, dh * f, dw, dh))
         else:
@@ -207,6 +210,10 @@ def test_random_device_batches_match_oracle(seed):
     filt = [None, None, "cubic", "triangle", "lanczos", "mitchel"][int(rng.integers(0, 6))]
     opts = {} if filt is None else {"filter": filt}
     chain_to = PIXELS[int(rng.integers(0, 8))] if rng.integers(0, 3) == 0 else None
+    if chain_to and any(g[2] > g[0] for g in geoms) and rng.integers(0, 2):   # a pair the one-kernel convert -> upscale form is instantiated for
+        pixel, chain_to = [("rgba", "rgb"), ("grey", "rgb"), ("r16g16b16", "rgb"), ("r16g16b16a16", "rgb"), ("rgb", "rgba"), ("greya", "rgba"), ("r16g16b16a16", "rgba"),
+                           ("rgb", "grey"), ("rgba", "grey"), ("greya", "grey"), ("r16", "grey")][int(rng.integers(0, 11))]
+        bpp = N.PIXEL_BYTES[pixel]
     order = int(rng.integers(0, 2))
     n = int(rng.integers(2, 7))
     which = [int(rng.integers(0, len(geoms))) for _ in range(n)]
@@ -246,6 +253,7 @@ def test_random_device_batches_match_oracle(seed):
     set_opt("run_xch", int(rng.choice([0, 1, 2])))
     set_opt("run_phase", int(rng.choice([0, 5, 12, 20])))
     set_opt("up", int(rng.choice([0, 1, 2])))
+    set_opt("fuse", int(rng.choice([0, 1, 1, 2])))
     if chain_to:
         N.check(L.picha_hip_convert_resize_device(n, S, D, order, r, g, b, ftag, fscale, stream))
     else:
