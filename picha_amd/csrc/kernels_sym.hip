@@ -146,8 +146,16 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
 #pragma unroll
                 for (int q = 0; q < C::SPAN; ++q) {
                     float u[CH];
+#ifdef PICHA_SYM_ABLATE_HALO   // measurement builds only (wrong results): the halo pixels of a lane's window cost no unpack — the upper bound of what handing
+                    // unpacked pixels between lanes could save
+                    constexpr int AHL = (TX - SX - 1) / 2, AOWN = SX * P;
+                    const int qq = q < AHL ? AHL : q >= AHL + AOWN ? AHL + AOWN - 1 : q;
+                    if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, qq, u);
+                    else unpack_span_px<C, CH, S16, FMA>(raw[bi], qq, u);
+#else
                     if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, q, u);
                     else unpack_span_px<C, CH, S16, FMA>(raw[bi], q, u);
+#endif
 #pragma unroll
                     for (int o = 0; o < P; ++o) {
                         const int j = q - SX * o;  // tap index of span pixel q for output o

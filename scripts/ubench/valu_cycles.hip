@@ -1,6 +1,7 @@
 // Microbenchmark 2: cycles per wave-instruction per SIMD for the VALU forms the resize kernel
 // can use, measured with s_memtime inside the kernel (independent of DVFS), 8 resident waves/SIMD.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -19,7 +20,8 @@
         for (int i = 0; i < iters; ++i) { asm volatile(REP8(ASM) : __VA_ARGS__); }                   \
         unsigned long long t1 = __builtin_amdgcn_s_memtime();                                        \
         unsigned long long rt1 = __builtin_amdgcn_s_memrealtime();                                   \
-        if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0; cyc[gridDim.x * 4 + blockIdx.x * 4 + (threadIdx.x >> 6)] = rt1 - rt0; } \
+        if ((threadIdx.x & 63) == 0) { cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0; cyc[gridDim.x * 4 + blockIdx.x * 4 + (threadIdx.x >> 6)] = rt1 - rt0; \
+            cyc[gridDim.x * 8 + blockIdx.x * 4 + (threadIdx.x >> 6)] = rt0; cyc[gridDim.x * 12 + blockIdx.x * 4 + (threadIdx.x >> 6)] = rt1; } \
         out[blockIdx.x * 256 + threadIdx.x] = a0 + a1 + a2 + a3 + (float)(d0 + d1 + d2 + d3) + r0 + r1; \
     }
 
@@ -55,6 +57,12 @@ DEFK(k_addu_s, "v_add_u32 %0, %4, %0\n v_add_u32 %1, %4, %1\n v_add_u32 %0, %4, 
 DEFK(k_fma_s, "v_fma_f32 %0, %4, %1, %0\n v_fma_f32 %1, %4, %2, %1\n v_fma_f32 %2, %4, %3, %2\n v_fma_f32 %3, %4, %0, %3\n", "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "s"(s))
 DEFK(k_fmac_dpp, "v_fmac_f32_dpp %0, %4, %1 row_shr:1 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %1, %4, %2 row_shr:1 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %2, %4, %3 row_shr:1 row_mask:0xf bank_mask:0xf\n v_fmac_f32_dpp %3, %4, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n", "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(s))
 
+// r04 mixes: does a half-rate class overlap with the multiply-add pipe, or do the costs add up?  (4 instructions per body; sum model: the per-class cycles averaged)
+DEFK(k_mix_cvt13, "v_cvt_f32_ubyte0 %0, %4\n v_mul_f32 %1, %1, %5\n v_add_f32 %2, %2, %5\n v_mul_f32 %3, %3, %5\n", "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(r0), "v"(s))
+DEFK(k_mix_cvt22, "v_cvt_f32_ubyte0 %0, %4\n v_mul_f32 %1, %1, %5\n v_cvt_f32_ubyte1 %2, %4\n v_add_f32 %3, %3, %5\n", "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(r0), "v"(s))
+DEFK(k_mix_sdwa13, "v_mul_f32_sdwa %0, %4, %5 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n v_mul_f32 %1, %1, %5\n v_add_f32 %2, %2, %5\n v_mul_f32 %3, %3, %5\n", "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(r0), "v"(s))
+DEFK(k_mix_muladd, "v_mul_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_mul_f32 %2, %2, %4\n v_add_f32 %3, %3, %4\n", "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(s))
+DEFK(k_mix_med13, "v_med3_f32 %0, %0, %4, %1\n v_mul_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n", "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(s))
 typedef void (*kfn)(unsigned long long *, float *, int, float, unsigned);
 struct Case { const char *name; kfn fn; };
 
@@ -64,14 +72,20 @@ int main() {
                     {"v_cvt_f32_u32_sdwa", k_cvtsdwa}, {"v_med3_f32", k_med3}, {"v_max_f32", k_max}, {"v_cvt_u32_f32", k_cvtu},
                     {"v_cvt_pk_u8_f32", k_cvtpku8}, {"v_perm_b32", k_perm}, {"v_lshl_or_b32", k_lshlor}, {"v_or_b32", k_or},
                     {"v_mov_b32", k_mov}, {"v_mov_b32_dpp row_shr", k_movdpp}, {"v_mov_b32_dpp wave_shr", k_movwshr},
-                    {"v_cvt_f32_ubyteN_dpp", k_cvtdpp}, {"v_mul_f32_dpp", k_muldpp}, {"v_mul_f32_sdwa", k_mulsdwa}, {"v_mul_f32 literal", k_mul_lit}, {"v_add_f32 inline 0.5", k_add_inl}, {"v_add_u32", k_addu}, {"v_add_u32 sgpr", k_addu_s}, {"v_fma_f32 sgpr", k_fma_s}, {"v_fmac_f32_dpp", k_fmac_dpp}};
+                    {"v_cvt_f32_ubyteN_dpp", k_cvtdpp}, {"v_mul_f32_dpp", k_muldpp}, {"v_mul_f32_sdwa", k_mulsdwa}, {"mix 1 cvt_ubyte : 3 mul/add", k_mix_cvt13}, {"mix 2 cvt_ubyte : 2 mul/add", k_mix_cvt22}, {"mix 1 mul_sdwa : 3 mul/add", k_mix_sdwa13}, {"mix mul add mul add", k_mix_muladd}, {"mix 1 med3 : 3 mul/add", k_mix_med13}, {"v_mul_f32 literal", k_mul_lit}, {"v_add_f32 inline 0.5", k_add_inl}, {"v_add_u32", k_addu}, {"v_add_u32 sgpr", k_addu_s}, {"v_fma_f32 sgpr", k_fma_s}, {"v_fmac_f32_dpp", k_fmac_dpp}};
     const int iters = 20000;
-    for (int wps : {8}) {          // waves per SIMD
+    // r04: waves per SIMD 1 .. 8, and how many waves were really resident at once: the sum of the waves' own durations over the span from the first start to
+    // the last end (s_memrealtime, chip-wide) per SIMD.  (The r01 table divided a wave's ticks by 8 "resident" waves; see profiles/r04_ubench_valu_rates.txt.)
+    const bool brief = true;
+    for (int wps : {1, 2, 4, 8}) {          // waves per SIMD asked for
         const int blocks = 256 * wps;    // 256-thread blocks = 1 wave per SIMD each
         unsigned long long *cyc; float *out;
-        hipMalloc(&cyc, blocks * 4 * 8 * 2); hipMalloc(&out, blocks * 256 * 4);
-        printf("---- %d wave(s) per SIMD: cycles per wave-instruction per SIMD ----\n", wps);
+        hipMalloc(&cyc, blocks * 4 * 8 * 4); hipMalloc(&out, blocks * 256 * 4);
+        printf("---- %d wave(s) per SIMD asked for ----\n", wps);
+        int idx = 0;
         for (auto &c : cases) {
+            ++idx;
+            if (brief && wps != 8 && idx > 5 && strcmp(c.name, "v_cvt_f32_ubyteN") && strcmp(c.name, "v_med3_f32") && strcmp(c.name, "v_mul_f32_sdwa")) continue;
             hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
             c.fn<<<blocks, 256>>>(cyc, out, 10, 1.0001f, 0x03020100u);
             hipDeviceSynchronize();
@@ -79,12 +93,17 @@ int main() {
             c.fn<<<blocks, 256>>>(cyc, out, iters, 1.0001f, 0x03020100u);
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms = 0; hipEventElapsedTime(&ms, e0, e1);
-            std::vector<unsigned long long> h(blocks * 4 * 2);
-            hipMemcpy(h.data(), cyc, blocks * 4 * 8 * 2, hipMemcpyDeviceToHost);
-            double sum = 0, rsum = 0; for (int i = 0; i < blocks * 4; ++i) { sum += h[i]; rsum += h[blocks * 4 + i]; }
-            double per_wave = sum / (blocks * 4), rt = rsum / (blocks * 4);
-            printf("%-26s %6.2f memtime-ticks  tick-rate %.2f GHz-by-realtime | in-kernel %.3f ms/wave, kernel wall %.3f ms -> WALL %.2f ns per wave-instr per SIMD\n", c.name, per_wave / (iters * 32.0) / wps,
-                   per_wave / (rt * 10.0), rt * 1e-5, ms, ms * 1e6 / (iters * 32.0) / wps);
+            std::vector<unsigned long long> h(blocks * 4 * 4);
+            hipMemcpy(h.data(), cyc, blocks * 4 * 8 * 4, hipMemcpyDeviceToHost);
+            double sum = 0, rsum = 0; unsigned long long first = ~0ull, last = 0;
+            for (int i = 0; i < blocks * 4; ++i) { sum += h[i]; rsum += h[blocks * 4 + i]; first = std::min(first, h[blocks * 8 + i]); last = std::max(last, h[blocks * 12 + i]); }
+            const double per_wave = sum / (blocks * 4), rt = rsum / (blocks * 4);
+            const double span = double(last - first);                 // 10 ns ticks
+            const double resident = rsum / span / 1024.0;             // average waves in flight per SIMD
+            const double clock = per_wave / (rt * 10.0);              // GHz
+            const double ns_per_instr_simd = span * 10.0 / (iters * 32.0) / wps;   // by the chip-wide clock: all SIMDs run wps waves' worth of instructions within the span
+            printf("%-26s in-kernel %.3f ms/wave, span %.3f ms, event %.3f ms | %.2f waves resident per SIMD | clock %.2f GHz | %.2f ns = %.2f cycles per wave-instruction per SIMD\n", c.name,
+                   rt * 1e-5, span * 1e-5, ms, resident, clock, ns_per_instr_simd, ns_per_instr_simd * clock);
         }
         hipFree(cyc); hipFree(out);
     }
