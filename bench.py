@@ -411,6 +411,10 @@ def main():
                 "max_launch_ms": round(sorted_ms[-1], 4),
                 "median_frac": round(alg_bytes / (median_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "read_only_frac": round(read_b / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                # what actually limits the kernel (measured, not part of the roofline definition of SURVEY.md 8d): profiles/r04_issue_models.txt
+                "note": ("fma flavour: at the time of its memory access pattern (profiles/r04_ubench_march_pattern.txt)" if numerics == "fma" else
+                         "bit-exact flavour: VALU-issue-bound where the source is 8-bit or the window long (issue time 80-120 % of the kernel time at the in-kernel "
+                         "clock, profiles/r04_issue_models.txt); cfg5 and the colour converts sit at their memory access pattern"),
             },
         }
         if other is not None:
