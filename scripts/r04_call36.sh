@@ -1,0 +1,22 @@
+#!/bin/bash
+# r04 call 36: 16-bit kernels built without the compiler's SDWA peephole (nosdwa) and, beyond that, without the asm SDWA multiply of the denormal unpack (nosdwa16: results of the
+# bit-exact flavour are wrong in that build — the host still scales its weights), against the in-tree build
+export PYTHONPATH=. TMPDIR=/tmp
+mkdir -p gpurun_out/r04
+out=gpurun_out/r04/call36_nosdwa.txt; : > $out
+for rnd in 1 2; do for lib in "" picha_amd/variants/libpicha_hip_nosdwa.so picha_amd/variants/libpicha_hip_nosdwa16.so; do
+  echo "== round $rnd lib=${lib:-in-tree}" >> $out
+  for w in cfg5_8k_rgba16_to_1080p_mitchel edge_deep_png_4k_rgba16_to_1080p_rgba; do
+  PICHA_HIP_LIB=$lib timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --workload $w 2>/dev/null | python -c "
+import sys,json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d=json.loads(l); o=d.get('other_numerics') or {}
+        print('%-44s %-66s ms/launch %8.4f frac %.4f parity %s | fma %s' % ('$w', d['config']['kernel'][:66], d['roofline']['avg_launch_ms'], d['roofline']['frac'], d['config'].get('parity_max_code_diff_vs_oracle_first2_images_all_ranks'), ('%.4f ms frac %.4f' % (o['avg_launch_ms'], o['roofline_frac'])) if o else '-'))
+" >> $out
+  done
+  for shape in 64:r16g16b16a16:3840:2160:1920:1080 128:r16:3840:2160:1920:1080 128:r16g16:3840:2160:1920:1080 64:r16g16b16:3840:2160:1920:1080; do
+  PICHA_HIP_LIB=$lib timeout -k 10 200 python scripts/ab_opts.py '[{}, {"numerics": 1}]' '' $shape 2 10 2>/dev/null | grep -v "^#" | sed "s/^/$shape  /" >> $out
+  done
+done; done
+cat $out
