@@ -29,7 +29,7 @@
 #endif
 // measurement builds only (scripts/r04_ablate.sh; results are wrong by construction): 1 = loads and stores without the arithmetic,
 // 2 = arithmetic and stores without the loads in the loop, 3 = no halo exchange (the lane's own pixels stand in for its neighbours'),
-// 4 = everything but the output stores (one row per chunk is stored)
+// 4 = everything but the output stores (one row per chunk is stored), 5 = window pixels outside the lane's own cost no unpack
 #ifndef PICHA_RUN_ABLATE
 #define PICHA_RUN_ABLATE 0
 #endif
@@ -497,8 +497,16 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
 #pragma unroll
         for (int q = 0; q < C::SPAN; ++q) {
             float u[CH];
+#if PICHA_RUN_ABLATE == 5   // measurement only (wrong results): the window pixels outside the lane's own (P / Q) * PX cost no unpack — the upper bound of what handing
+            // running sums (or unpacked pixels) between neighbouring lanes could save
+            constexpr int AOWN = (P / Q) * PX, AOFF = (C::SPAN - AOWN) / 2;
+            const int qa = q < AOFF ? AOFF : q >= AOFF + AOWN ? AOFF + AOWN - 1 : q;
+            if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, qa, u);
+            else unpack_span_px<C, CH, S16, FMA>(cur, qa, u);
+#else
             if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, q, u);
             else unpack_span_px<C, CH, S16, FMA>(cur, q, u);
+#endif
 #pragma unroll
             for (int o = 0; o < P; ++o) {
                 const int j = q - run_off(Q, PX, o, RC);  // tap index of window pixel q for output o
