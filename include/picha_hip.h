@@ -224,8 +224,9 @@ int picha_hip_resize_batch(int n, const picha_image *src, const picha_image *dst
  * library that changes RESULTS — the numerics flavour — can be chosen per call too, so that two callers in one process (one Node
  * process serving two pipelines) do not have to agree on it.  `size` = sizeof(picha_call_opts) (forward compatibility);
  * numerics: -1 = the process-wide "numerics" option, 0 = reference arithmetic (bit-identical), 1 = fused multiply-add flavour
- * (at most one code value from the reference).  opts == NULL behaves like the plain entry point.  The asynchronous entry
- * points take the process-wide option at enqueue time.
+ * (at most one code value from the reference).  opts == NULL behaves like the plain entry point.  picha_hip_resize_async_ex carries
+ * the choice with the request (the dispatcher batches requests of equal options together); the plain asynchronous entry points take
+ * the process-wide option when their batch is launched.
  */
 typedef struct picha_call_opts {
     int32_t size;
@@ -254,6 +255,9 @@ int picha_hip_resize_async(const picha_image *src, const picha_image *dst, int f
                            float filter_scale, picha_hip_done_fn done, void *user);
 int picha_hip_color_convert_async(const picha_image *src, const picha_image *dst, float r_factor,
                                   float g_factor, float b_factor, picha_hip_done_fn done, void *user);
+/* picha_hip_resize_async with per-call options (picha_call_opts above): the reference's options are per call, src/resize.cc:179-198 */
+int picha_hip_resize_async_ex(const picha_image *src, const picha_image *dst, int filter, float filter_scale,
+                              const picha_call_opts *opts, picha_hip_done_fn done, void *user);
 /* Blocks until every request queued so far has completed (tests, orderly shutdown). */
 int picha_hip_async_drain(void);
 /* Number of batches the dispatcher has launched and of requests it has completed (diagnostics). */

@@ -73,6 +73,7 @@ SYMBOLS = [
     ("picha_hip_resize_batch_ex", _i, [_i, _P, _P, _i, _f, _vp]),
     ("picha_hip_color_convert_batch", _i, [_i, _P, _P, _f, _f, _f]),
     ("picha_hip_resize_async", _i, [_P, _P, _i, _f, _vp, _vp]),
+    ("picha_hip_resize_async_ex", _i, [_P, _P, _i, _f, _vp, _vp, _vp]),
     ("picha_hip_color_convert_async", _i, [_P, _P, _f, _f, _f, _vp, _vp]),
     ("picha_hip_async_drain", _i, []),
     ("picha_hip_async_stats", None, [ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64)]),

@@ -178,14 +178,20 @@ def resizeSync(image, opts, numerics=None):
     return _run_resize(src, dst, ftag, fscale, numerics)
 
 
-def resize(image, opts, cb):
+def resize(image, opts, cb, numerics=None):
+    """picha.resize.  `numerics` ("exact" / "fma"): per-call extension as for resizeSync (picha_hip_resize_async_ex: the request carries it)."""
     if not callable(cb):
         raise PichaError("expected: resize(image, opts, cb)")
     src, dst, ftag, fscale = _prepare_resize(image, opts, "expected: resize(image, opts, cb)")
     cdst = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index(dst.pixel))
     L = N.lib()
-    _submit_async(lambda done, user: L.picha_hip_resize_async(ctypes.byref(src[0]), ctypes.byref(cdst), ftag, fscale, done, user),
-                  src, dst, cb)
+    if numerics is None:
+        _submit_async(lambda done, user: L.picha_hip_resize_async(ctypes.byref(src[0]), ctypes.byref(cdst), ftag, fscale, done, user),
+                      src, dst, cb)
+    else:
+        co = N.CCallOpts(numerics)
+        _submit_async(lambda done, user: L.picha_hip_resize_async_ex(ctypes.byref(src[0]), ctypes.byref(cdst), ftag, fscale, ctypes.byref(co), done, user),
+                      src, dst, cb)
 
 
 def _color_settings(opts):

@@ -50,10 +50,11 @@ struct Request {
     int filter;
     float fscale;   // resize / chained
     float r, g, b;  // colorConvert / chained
+    int numerics;   // resize: -1 = the process-wide option when the batch is launched, 0 / 1 = this request's own (picha_hip_resize_async_ex)
     picha_hip_done_fn done;
     void *user;
     bool compatible(const Request &o) const {
-        return kind == o.kind && order == o.order && filter == o.filter && fscale == o.fscale && r == o.r && g == o.g && b == o.b;
+        return kind == o.kind && order == o.order && filter == o.filter && fscale == o.fscale && r == o.r && g == o.g && b == o.b && numerics == o.numerics;
     }
 };
 
@@ -241,7 +242,8 @@ private:
         int rc = PICHA_OK;
         if (e == hipSuccess) {
             const Request &r0 = s.reqs[0];
-            rc = r0.kind == 1   ? picha_hip_resize_device(n, dsrc.data(), ddst.data(), r0.filter, r0.fscale, s.stream)
+            const picha_call_opts co{(int32_t)sizeof(picha_call_opts), r0.numerics};
+            rc = r0.kind == 1   ? picha_hip_resize_device_ex(n, dsrc.data(), ddst.data(), r0.filter, r0.fscale, r0.numerics >= 0 ? &co : nullptr, s.stream)
                  : r0.kind == 0 ? picha_hip_color_convert_device(n, dsrc.data(), ddst.data(), r0.r, r0.g, r0.b, s.stream)
                                 : picha_hip_convert_resize_device(n, dsrc.data(), ddst.data(), r0.order, r0.r, r0.g, r0.b,
                                                                   r0.filter, r0.fscale, s.stream);
@@ -324,7 +326,7 @@ extern "C" int picha_hip_validate_host_op(int kind, const picha_image *src, cons
                                           float filter_scale, int *device);
 
 int submit(int kind, int order, const picha_image *src, const picha_image *dst, int filter, float fscale, float r, float g,
-           float b, picha_hip_done_fn done, void *user) {
+           float b, picha_hip_done_fn done, void *user, int numerics = -1) {
     int dev = 0;
     int rc = picha_hip_validate_host_op(kind, src, dst, filter, fscale, &dev);
     if (rc != PICHA_OK) return rc;
@@ -354,6 +356,7 @@ int submit(int kind, int order, const picha_image *src, const picha_image *dst, 
     q.filter = filter;
     q.fscale = fscale;
     q.r = r; q.g = g; q.b = b;
+    q.numerics = numerics;
     q.done = done;
     q.user = user;
     dispatcher_for(slot, phys)->enqueue(q);
@@ -370,6 +373,16 @@ extern "C" {
 int picha_hip_resize_async(const picha_image *src, const picha_image *dst, int filter, float filter_scale,
                            picha_hip_done_fn done, void *user) {
     return submit(1, 0, src, dst, filter, filter_scale, 0.0f, 0.0f, 0.0f, done, user);
+}
+
+int picha_hip_resize_async_ex(const picha_image *src, const picha_image *dst, int filter, float filter_scale, const picha_call_opts *opts,
+                              picha_hip_done_fn done, void *user) {
+    int numerics = -1;
+    if (opts) {
+        if (opts->size < (int32_t)sizeof(picha_call_opts) || opts->numerics < -1 || opts->numerics > 1) return PICHA_ERR_ARGUMENT;
+        numerics = opts->numerics;
+    }
+    return submit(1, 0, src, dst, filter, filter_scale, 0.0f, 0.0f, 0.0f, done, user, numerics);
 }
 
 int picha_hip_color_convert_async(const picha_image *src, const picha_image *dst, float r, float g, float b,

@@ -147,6 +147,7 @@ typedef struct op_ctx {
     int filter;
     float filter_scale;
     float cs[3];
+    int numerics;  /* resize only: -1 = the process-wide option, 0 reference arithmetic, 1 fma — opts.numerics ('exact' / 'fma'), this library's per-call extension (picha_call_opts) */
     /* async only */
     napi_threadsafe_function tsfn;
     napi_ref src_ref, dst_ref;
@@ -157,7 +158,10 @@ typedef struct op_ctx {
 static void run_op(op_ctx *c) {
     if (c->is_resize == 2)
         c->status = picha_hip_convert_resize(&c->src, &c->dst, c->order, c->cs[0], c->cs[1], c->cs[2], c->filter, c->filter_scale);
-    else if (c->is_resize) c->status = picha_hip_resize(&c->src, &c->dst, c->filter, c->filter_scale);
+    else if (c->is_resize) {
+        picha_call_opts co = { (int32_t)sizeof co, c->numerics };
+        c->status = picha_hip_resize_ex(&c->src, &c->dst, c->filter, c->filter_scale, c->numerics >= 0 ? &co : NULL);
+    }
     else c->status = picha_hip_color_convert(&c->src, &c->dst, c->cs[0], c->cs[1], c->cs[2]);
     if (c->status != PICHA_OK) {
         const char *m = picha_hip_last_error(); /* thread-local: read it on the thread that failed */
@@ -252,6 +256,18 @@ static int prepare(napi_env env, napi_value img, napi_value opts, op_ctx *c, nap
         }
         int rc = picha_resize_options(has_filter, tag, has_scale, scale, &c->filter, &c->filter_scale);
         if (rc != PICHA_OK) { throw_msg(env, picha_hip_strerror(rc)); return 0; }
+        /* opts.numerics: not a reference option (the reference has one arithmetic); absent = the library's process-wide choice */
+        c->numerics = -1;
+        napi_value nm = get_prop(env, opts, "numerics");
+        if (!is_undefined(env, nm)) {
+            napi_valuetype t;
+            char buf[16];
+            size_t len;
+            if (napi_typeof(env, nm, &t) == napi_ok && t == napi_string && napi_get_value_string_utf8(env, nm, buf, sizeof buf, &len) == napi_ok &&
+                (strcmp(buf, "exact") == 0 || strcmp(buf, "fma") == 0))
+                c->numerics = strcmp(buf, "fma") == 0;
+            else { throw_msg(env, "invalid numerics (expected 'exact' or 'fma')"); return 0; }
+        }
     }
     if (c->is_resize == 2) { /* opts.order: 'resizeFirst' resizes in the source format, then converts */
         napi_value o = get_prop(env, opts, "order");
@@ -307,7 +323,7 @@ static napi_value do_async(napi_env env, napi_callback_info info, int is_resize,
     /* hand the request to the library's batching dispatcher (replaces uv_queue_work, src/resize.cc:362-364) */
     int rc = c->is_resize == 2 ? picha_hip_convert_resize_async(&c->src, &c->dst, c->order, c->cs[0], c->cs[1], c->cs[2], c->filter,
                                                                 c->filter_scale, async_done, c)
-             : c->is_resize    ? picha_hip_resize_async(&c->src, &c->dst, c->filter, c->filter_scale, async_done, c)
+             : c->is_resize    ? picha_hip_resize_async_ex(&c->src, &c->dst, c->filter, c->filter_scale, c->numerics >= 0 ? &(picha_call_opts){ (int32_t)sizeof(picha_call_opts), c->numerics } : NULL, async_done, c)
                                : picha_hip_color_convert_async(&c->src, &c->dst, c->cs[0], c->cs[1], c->cs[2], async_done, c);
     if (rc != PICHA_OK) { /* rejected synchronously, e.g. no device: throw like every other argument problem */
         char msg[512];

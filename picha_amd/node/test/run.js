@@ -87,6 +87,7 @@ test('argument errors', () => {
 	throwsMsg(() => picha.resizeSync(img, { width: 2, height: 2, filter: 1 }), 'invalid filter mode');
 	throwsMsg(() => picha.resizeSync(img, { width: 2, height: 2, filterScale: 0 }), 'invalid filter width');
 	throwsMsg(() => picha.resizeSync(img, { width: 2, height: 2, filterScale: 'wide' }), 'invalid filter width');
+	throwsMsg(() => picha.resizeSync(img, { width: 2, height: 2, numerics: 'fast' }), "invalid numerics (expected 'exact' or 'fma')");
 	throwsMsg(() => picha.colorConvertSync(img, {}), 'expected pixel mode');
 	throwsMsg(() => picha.colorConvertSync(img, { pixel: 'cmyk' }), 'expected pixel mode');
 	throwsMsg(() => picha.convertResizeSync(img), 'expected: convertResizeSync(image, opts)');
@@ -150,6 +151,19 @@ if (!haveGpu) {
 		picha.convertResize(image, o, (err, a) => {
 			if (err) return done(err);
 			try { assert(a.equalPixels(picha.convertResizeSync(image, o))); done(); } catch (e) { done(e); }
+		});
+	});
+	test("opts.numerics is per call: 'exact' is the reference's arithmetic, 'fma' stays within one code value (sync and async)", (done) => {
+		const exact = picha.resizeSync(image, { width: 32, height: 24, numerics: 'exact' });
+		assert(exact.equalPixels(smallImage));
+		const fma = picha.resizeSync(image, { width: 32, height: 24, numerics: 'fma' });
+		assert(fma.avgChannelDiff(smallImage) <= 1);
+		picha.resize(image, { width: 32, height: 24, numerics: 'fma' }, (err, a) => {
+			if (err) return done(err);
+			picha.resize(image, { width: 32, height: 24, numerics: 'exact' }, (err2, b) => {
+				if (err2) return done(err2);
+				try { assert(a.equalPixels(fma)); assert(b.equalPixels(smallImage)); done(); } catch (e) { done(e); }
+			});
 		});
 	});
 	test('resize: every filter and a 16-bit format run', () => {

@@ -33,6 +33,7 @@ static int fake_op(int n, const picha_image *src, const picha_image *dst, unsign
     return PICHA_OK;
 }
 int picha_hip_resize_device(int n, const picha_image *s, const picha_image *d, int, float, void *) { return fake_op(n, s, d, 0x11); }
+int picha_hip_resize_device_ex(int n, const picha_image *s, const picha_image *d, int, float, const picha_call_opts *, void *) { return fake_op(n, s, d, 0x11); }
 int picha_hip_color_convert_device(int n, const picha_image *s, const picha_image *d, float, float, float, void *) { return fake_op(n, s, d, 0x22); }
 int picha_hip_convert_resize_device(int n, const picha_image *s, const picha_image *d, int, float, float, float, int, float, void *) { return fake_op(n, s, d, 0x33); }
 const char *picha_hip_last_error(void) { return "mock"; }

@@ -1090,6 +1090,49 @@ def test_per_call_numerics_override_the_process_option():
         set_opt("numerics", 0)
 
 
+def test_per_call_numerics_travel_with_asynchronous_requests():
+    """r04: picha_hip_resize_async_ex — a request carries its numerics flavour through the batching dispatcher (requests of different
+    flavours never share a batch), whatever the process-wide option is: reference-flavour requests must equal the oracle bit for bit
+    while fma-flavour requests are in flight beside them, and the fma ones must differ from it somewhere (they really ran as fma)."""
+    import threading
+    rng = np.random.default_rng(405)
+    imgs = [rand_image(rng, 640 + 2 * (k % 5), 96 + k % 7, "rgba") for k in range(24)]
+    wants = [oracle_resize(im, im.width // 2, im.height // 2) for im in imgs]
+    got, done = {}, threading.Event()
+    lock = threading.Lock()
+    def make_cb(k):
+        def cb(err, out):
+            with lock:
+                got[k] = (err, out)
+                if len(got) == len(imgs): done.set()
+        return cb
+    try:
+        set_opt("numerics", 1)   # the process-wide default says fma: the even requests ask for the reference arithmetic themselves
+        for k, im in enumerate(imgs):
+            picha_amd.resize(im, {"width": im.width // 2, "height": im.height // 2}, make_cb(k), numerics="exact" if k % 2 == 0 else "fma")
+        assert done.wait(60)
+        fma_differs = 0
+        for k in range(len(imgs)):
+            err, out = got[k]
+            assert err is None, err
+            d = max_code_diff(out, wants[k])
+            if k % 2 == 0: assert d == 0, (k, d)
+            else:
+                assert d <= 1, (k, d)
+                fma_differs += d
+        assert fma_differs > 0
+        bad = N.CCallOpts(0); bad.numerics = 5
+        im = imgs[0]
+        import ctypes
+        dst = picha_amd.Image(width=im.width // 2, height=im.height // 2, pixel="rgba")
+        cs = N.CImage(im.data.ctypes.data, im.stride, im.width, im.height, N.pixel_index("rgba"))
+        cd = N.CImage(dst.data.ctypes.data, dst.stride, dst.width, dst.height, N.pixel_index("rgba"))
+        assert N.lib().picha_hip_resize_async_ex(ctypes.byref(cs), ctypes.byref(cd), 0, 0.7, ctypes.byref(bad), None, None) != 0
+    finally:
+        set_opt("numerics", 0)
+        N.lib().picha_hip_async_drain()
+
+
 def test_work_item_lists_survive_eviction_under_concurrent_callers():
     """r04: the work-item list cache holds 64 geometries; threads that cycle through more than that while
     others launch with lists taken just before must never see a freed list (shared ownership, one LRU entry evicted at a time,
