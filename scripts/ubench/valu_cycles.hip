@@ -69,6 +69,9 @@ DEFK(k_mix_dpp13, "v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf\n 
 DEFK(k_mix_align13, "v_alignbyte_b32 %0, %0, %1, 1\n v_mul_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n", "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(s))
 DEFK(k_mix_cvtu32_13, "v_cvt_f32_u32 %0, %5\n v_mul_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n", "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(s), "v"(r0))
 DEFK(k_mix_cvtpk13, "v_cvt_pk_u8_f32 %0, %4, 0, %0\n v_mul_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_mul_f32 %3, %3, %4\n", "+v"(r0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(s))
+DEFK(k_mix_pk13, "v_pk_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %5\n v_add_f32 %2, %2, %5\n v_mul_f32 %3, %3, %5\n", "+v"(d0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(d2), "v"(s))
+DEFK(k_mix_pk22, "v_pk_mul_f32 %0, %0, %4\n v_mul_f32 %1, %1, %5\n v_pk_mul_f32 %2, %2, %4\n v_add_f32 %3, %3, %5\n", "+v"(d0), "+v"(a1), "+v"(d1), "+v"(a3) : "v"(d2), "v"(s))
+DEFK(k_mix_pkfma13, "v_pk_fma_f32 %0, %0, %4, %4\n v_mul_f32 %1, %1, %5\n v_add_f32 %2, %2, %5\n v_mul_f32 %3, %3, %5\n", "+v"(d0), "+v"(a1), "+v"(a2), "+v"(a3) : "v"(d2), "v"(s))
 typedef void (*kfn)(unsigned long long *, float *, int, float, unsigned);
 struct Case { const char *name; kfn fn; };
 
@@ -78,7 +81,7 @@ int main() {
                     {"v_cvt_f32_u32_sdwa", k_cvtsdwa}, {"v_med3_f32", k_med3}, {"v_max_f32", k_max}, {"v_cvt_u32_f32", k_cvtu},
                     {"v_cvt_pk_u8_f32", k_cvtpku8}, {"v_perm_b32", k_perm}, {"v_lshl_or_b32", k_lshlor}, {"v_or_b32", k_or},
                     {"v_mov_b32", k_mov}, {"v_mov_b32_dpp row_shr", k_movdpp}, {"v_mov_b32_dpp wave_shr", k_movwshr},
-                    {"v_cvt_f32_ubyteN_dpp", k_cvtdpp}, {"v_mul_f32_dpp", k_muldpp}, {"v_mul_f32_sdwa", k_mulsdwa}, {"mix 1 cvt_ubyte : 3 mul/add", k_mix_cvt13}, {"mix 2 cvt_ubyte : 2 mul/add", k_mix_cvt22}, {"mix 1 mul_sdwa : 3 mul/add", k_mix_sdwa13}, {"mix mul add mul add", k_mix_muladd}, {"mix 1 med3 : 3 mul/add", k_mix_med13}, {"mix 1 sgpr-operand mul : 3 mul/add", k_mix_sgpr13}, {"mix 2 sgpr-operand mul : 2 add", k_mix_sgpr22}, {"mix 1 v_mov_dpp wave_shr : 3 mul/add", k_mix_dpp13}, {"mix 1 v_alignbyte : 3 mul/add", k_mix_align13}, {"mix 1 v_cvt_f32_u32 : 3 mul/add", k_mix_cvtu32_13}, {"mix 1 v_cvt_pk_u8_f32 : 3 mul/add", k_mix_cvtpk13}, {"v_mul_f32 literal", k_mul_lit}, {"v_add_f32 inline 0.5", k_add_inl}, {"v_add_u32", k_addu}, {"v_add_u32 sgpr", k_addu_s}, {"v_fma_f32 sgpr", k_fma_s}, {"v_fmac_f32_dpp", k_fmac_dpp}};
+                    {"v_cvt_f32_ubyteN_dpp", k_cvtdpp}, {"v_mul_f32_dpp", k_muldpp}, {"v_mul_f32_sdwa", k_mulsdwa}, {"mix 1 cvt_ubyte : 3 mul/add", k_mix_cvt13}, {"mix 2 cvt_ubyte : 2 mul/add", k_mix_cvt22}, {"mix 1 mul_sdwa : 3 mul/add", k_mix_sdwa13}, {"mix mul add mul add", k_mix_muladd}, {"mix 1 med3 : 3 mul/add", k_mix_med13}, {"mix 1 v_pk_mul_f32 : 3 mul/add", k_mix_pk13}, {"mix 2 v_pk_mul_f32 : 2 mul/add", k_mix_pk22}, {"mix 1 v_pk_fma_f32 : 3 mul/add", k_mix_pkfma13}, {"mix 1 sgpr-operand mul : 3 mul/add", k_mix_sgpr13}, {"mix 2 sgpr-operand mul : 2 add", k_mix_sgpr22}, {"mix 1 v_mov_dpp wave_shr : 3 mul/add", k_mix_dpp13}, {"mix 1 v_alignbyte : 3 mul/add", k_mix_align13}, {"mix 1 v_cvt_f32_u32 : 3 mul/add", k_mix_cvtu32_13}, {"mix 1 v_cvt_pk_u8_f32 : 3 mul/add", k_mix_cvtpk13}, {"v_mul_f32 literal", k_mul_lit}, {"v_add_f32 inline 0.5", k_add_inl}, {"v_add_u32", k_addu}, {"v_add_u32 sgpr", k_addu_s}, {"v_fma_f32 sgpr", k_fma_s}, {"v_fmac_f32_dpp", k_fmac_dpp}};
     const int iters = 20000;
     // r04: waves per SIMD 1 .. 8, and how many waves were really resident at once: the sum of the waves' own durations over the span from the first start to
     // the last end (s_memrealtime, chip-wide) per SIMD.  (The r01 table divided a wave's ticks by 8 "resident" waves; see profiles/r04_ubench_valu_rates.txt.)
