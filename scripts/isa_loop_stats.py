@@ -1,13 +1,14 @@
 """Instruction mix of a kernel's hot loop from the shipped code object: finds the largest backward-branch region of a kernel, counts
-instructions by class (with the issue cost per class measured in profiles/r01_ubench_valu_issue_rates.txt), lists the waits and nops.
+instructions by class (with the issue cost per class measured in profiles/r04_ubench_valu_rates.txt: every plain instruction one slot of 2.45 cycles inside a
+multiply-add stream, SDWA / DPP / packed-f32 forms ~8.7 because they stall it), lists the waits and nops.  STATIC counts: code of both sides of a branch is counted.
 
 usage: python scripts/isa_loop_stats.py <libpicha_hip.so | object file> <substring of the mangled kernel name> [rows per iteration]
 """
 import collections, os, re, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
-# issue ticks per wave-instruction per SIMD at 8 waves per SIMD (r01_ubench_valu_issue_rates.txt)
-COST = {"v_mul_f32": 1.38, "v_add_f32": 1.37, "v_fma_f32": 1.38, "v_fmac_f32": 1.38, "v_mul_f32 (sgpr operand)": 2.35, "v_fma_f32 (sgpr operand)": 2.45,
-        "sdwa": 2.38, "dpp": 2.38, "v_cvt": 1.69, "v_med3": 2.38, "v_alignbyte": 1.68, "v_mov": 1.37, "v_int": 0.88, "v_other": 1.7}
+# issue cycles per wave-instruction per SIMD (r04_ubench_valu_rates.txt; the r01 table this script first used was low by 1.8 x)
+COST = {"v_mul_f32": 2.45, "v_add_f32": 2.45, "v_fma_f32": 2.45, "v_fmac_f32": 2.45, "v_mul_f32 (sgpr operand)": 2.45, "v_fma_f32 (sgpr operand)": 2.45,
+        "sdwa": 8.7, "dpp": 8.7, "v_cvt": 2.45, "v_med3": 2.45, "v_alignbyte": 2.45, "v_mov": 2.45, "v_int": 2.45, "v_other": 2.45}
 
 
 def classify(op, rest):
@@ -76,14 +77,14 @@ def main():
     body = ins[j:i + 1]
     print("hot loop: %d instructions (%#x .. %#x), %d source row(s) per iteration" % (len(body), body[0][0], body[-1][0], rows))
     cnt = collections.Counter(classify(op, rest) for _, op, rest in body)
-    ticks = 0.0
+    cycles = 0.0
     for k in sorted(cnt, key=lambda k: -cnt[k]):
         c = COST.get(k)
         t = cnt[k] * c if c else 0.0
-        ticks += t
-        print("  %-28s %5d per iteration  %7.1f per row%s" % (k, cnt[k], cnt[k] / rows, "   x %.2f ticks = %7.1f per row" % (c, t / rows) if c else ""))
+        cycles += t
+        print("  %-28s %5d per iteration  %7.1f per row%s" % (k, cnt[k], cnt[k] / rows, "   x %.2f cycles = %7.1f per row" % (c, t / rows) if c else ""))
     nvalu = sum(v for k, v in cnt.items() if k in COST)
-    print("  VALU instructions per row: %.1f; issue ticks per row at the measured per-class rates: %.1f" % (nvalu / rows, ticks / rows))
+    print("  VALU instructions per row: %.1f; issue cycles per row at the measured per-class rates: %.1f" % (nvalu / rows, cycles / rows))
     waits = [(a, rest) for a, op, rest in body if op.startswith("s_waitcnt")]
     print("  s_waitcnt in the loop (%d):" % len(waits), ", ".join(r for _, r in waits))
     nops = [rest for _, op, rest in body if op.startswith("s_nop")]
