@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — throughput of picha's pixel hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N=1)
+    python bench.py --gpus N --steps K --warmup W          (N >= 1; for N > 1 it starts its own N ranks as a child torch.distributed.run)
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step = one pass of the hot path over one device-resident batch of synthetic images
@@ -136,6 +136,23 @@ def cpu_baseline(name):
     return out
 
 
+def spawn_ranks(n, argv):
+    """Run this script as n ranks under torch.distributed.run (rendezvous on 127.0.0.1, a free port) in a child process; returns its
+    exit code.  Must be called before anything in this process initialises the GPU."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL between processes needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "1")
+    print("bench.py: --gpus %d without a launcher: starting %d ranks: %s" % (n, n, " ".join(cmd)), file=sys.stderr)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -155,6 +172,13 @@ def main():
                          "(a cold process needs ~9 launches / 25 ms to reach steady state, profiles/r01_launch_series.txt)")
     ap.add_argument("--option", action="append", default=[], help="library knob key=value (e.g. row_chunks=4)")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` by itself (no launcher): become N ranks.  The parent has touched no GPU (torch is not even imported yet);
+    # it starts torch.distributed.run as a CHILD process — one rank per GPU over RCCL — hands it this command line unchanged and exits with
+    # its code.  Under a launcher (RANK set) this is skipped and the process is one of the ranks.  The only parallelism the reference has is
+    # one image per worker (src/resize.cc:362-364); here it is one shard of images per GPU.
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist

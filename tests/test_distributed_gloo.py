@@ -106,3 +106,39 @@ def test_eight_rank_sharding_of_the_baseline_batches_and_the_rank_report():
         assert res["cfg5"] == (128 * rank, 128 * (rank + 1), True)
         assert seen == world and n_ms == world and devs == ["gpu-%d" % r for r in range(world)] and dup == []
     assert len({r[2] for r in results}) == 1    # one max-over-ranks time
+
+
+def test_bench_gpus_n_spawns_n_ranks_before_touching_the_gpu(tmp_path):
+    """`python bench.py --gpus N` without a launcher must start N ranks by itself: the parent process builds a
+    torch.distributed.run command for 127.0.0.1 with --nproc-per-node N and this command line, runs it as a CHILD, returns its exit code —
+    and has not imported torch (let alone initialised a GPU) when it does so.  Checked here without a GPU by standing a recorder in for the
+    child's interpreter."""
+    import json
+    import subprocess
+    rec = tmp_path / "argv.json"
+    fake = tmp_path / "fakepy"
+    fake.write_text("#!/bin/sh\nprintf '%s\\n' \"$@\" > " + str(rec) + "\necho \"$RANK\" >> " + str(rec) + "\nexit 7\n")
+    fake.chmod(0o755)
+    code = (
+        "import sys, os\n"
+        "sys.argv = ['bench.py', '--gpus', '4', '--steps', '2', '--warmup', '1']\n"
+        "sys.path.insert(0, %r)\n"
+        "import bench\n"
+        "sys.executable = %r\n"
+        "try:\n"
+        "    bench.main()\n"
+        "except SystemExit as e:\n"
+        "    print('EXIT', e.code, 'torch' in sys.modules)\n" % (ROOT, str(fake)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert "EXIT 7 False" in out.stdout, (out.stdout, out.stderr[-2000:])   # the child's code comes back; torch never imported in the parent
+    argv = rec.read_text().split("\n")
+    assert argv[:3] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert argv[argv.index("--nproc-per-node") + 1] == "4" and argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    tail = argv[argv.index(os.path.join(ROOT, "bench.py")) + 1:]
+    assert tail[:6] == ["--gpus", "4", "--steps", "2", "--warmup", "1"]
+    # under a launcher (RANK set) the same command line does NOT spawn again
+    out = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench, inspect; "
+                          "src = inspect.getsource(bench.main); assert '\"RANK\" not in os.environ' in src" % ROOT],
+                         capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr

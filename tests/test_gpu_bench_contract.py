@@ -79,3 +79,20 @@ def test_bench_two_ranks_over_gloo_on_one_gpu():
     # whole-job value: both ranks' images over the max-over-ranks time
     assert abs(d["value"] - 2 * 8 * 3840 * 2160 * 3 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 0.01
     assert d["config"]["parity_max_code_diff_vs_oracle_image0"] == 0
+
+
+def test_bench_gpus_2_launches_its_own_two_ranks():
+    """`python bench.py --gpus 2` with NO launcher (the form the driver uses at N = 1): bench.py starts torch.distributed.run as a child
+    before it touches the GPU and the line that comes back is a two-rank line.  gloo because this box has one GPU."""
+    env = dict(os.environ, PICHA_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--images", "8", "--steps", "3", "--warmup", "1",
+                          "--prewarm-ms", "5", "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["ranks_seen"] == 2 and len(d["config"]["per_rank_ms"]) == 2
+    assert d["config"]["parallelism"] == "image-sharded x2" and d["config"]["parity_max_code_diff_vs_oracle_first2_images_all_ranks"] == 0
+    assert abs(d["value"] - 2 * 8 * 3840 * 2160 * 3 / (d["ms_per_step"] * 3 * 1e-3) / 1e6) / d["value"] < 0.01
