@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage: r04_build_variant.sh <tag> "<extra -D flags>" [pixels...]: rebuilds the run-kernel TUs of the given pixel formats (default 2 7) with extra
+# usage: build_variant.sh <tag> "<extra -D flags>" [pixels...]: rebuilds the run-kernel TUs of the given pixel formats (default 2 7) with extra
 # flags (and the symmetric-table TUs of the formats in $SYM_PIX) and links them with the in-tree objects into picha_amd/variants/libpicha_hip_<tag>.so (A/B of BUILDS on one box: PICHA_HIP_LIB)
 set -e
 tag=$1; flags=$2; shift 2; pix=${@:-2 7}
@@ -47,5 +47,9 @@ for n in 0 1 2 3 4 5 6 7 8 9 10 11; do
 done
 wait
 rest="$(ls build/*.o | grep -v "build/run_p" | grep -v "build/sym_p" | grep -v "build/rows_v" | grep -v "build/stream_p" | grep -v "build/span_p" | grep -v "build/kernels.o") $symobjs $rowsobjs $streamobjs $spanobjs $kobj"
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../variants/libpicha_hip_$tag.so $rest $objs
-ls -la ../variants/libpicha_hip_$tag.so
+# the library is linked into variants_stash/ (not shipped: gpurun's snapshot limit is 512 MiB and a build is 80 MB) and shipped as variants/<name>.so.xz (8 MB);
+# scripts/unpack_variants.sh restores variants/*.so on the GPU box
+mkdir -p ../../gpurun_out/variants_stash
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o ../../gpurun_out/variants_stash/libpicha_hip_$tag.so $rest $objs
+xz -1 -T4 -k -c ../../gpurun_out/variants_stash/libpicha_hip_$tag.so > ../variants/libpicha_hip_$tag.so.xz
+ls -la ../variants/libpicha_hip_$tag.so.xz

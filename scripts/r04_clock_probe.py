@@ -1,5 +1,5 @@
 """In-kernel shader clock of the resize kernels under their own load (MI355X guide, DVFS item 6): a diagnostic build
-(-DPICHA_CLOCK_PROBE, scripts/r04_build_variant.sh) stamps s_memtime / s_memrealtime at the start and end of every wave;
+(-DPICHA_CLOCK_PROBE, scripts/build_variant.sh) stamps s_memtime / s_memrealtime at the start and end of every wave;
 clock = sum(d memtime) / sum(d memrealtime) x 100 MHz, read after >= 2 s of back-to-back launches on random pixels.
 
 usage: PICHA_HIP_LIB=picha_amd/variants/libpicha_hip_probe.so python scripts/r04_clock_probe.py
@@ -57,8 +57,8 @@ def main():
                 plan.run()
             torch.cuda.synchronize()
             launches += 20
-        SLOTS = 1 << 17
-        out = (ctypes.c_ulonglong * (2 * SLOTS))()
+        SLOTS = 1 << 18
+        out = (ctypes.c_ulonglong * (4 * SLOTS))()   # r05: 4 words per wave (d memtime, d memrealtime, start, HW_ID | XCC_ID << 32)
         assert probe(out, 1) == SLOTS
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         reps = 100
@@ -69,7 +69,7 @@ def main():
         torch.cuda.synchronize()
         assert probe(out, 0) == SLOTS
         import numpy as np
-        a = np.frombuffer(out, dtype=np.uint64).reshape(SLOTS, 2).astype(np.float64)
+        a = np.frombuffer(out, dtype=np.uint64).reshape(SLOTS, 4)[:, :2].astype(np.float64)
         a = a[a[:, 1] > 0]
         if len(a) == 0:
             print("%-12s %s: no stamps (the kernel that ran lives in another translation unit than %s)" % (label, name, sym))
