@@ -389,6 +389,30 @@ def main():
                 stale = {"file": rel, "kernel": rec.get("kernel"), "stale": "measured on another kernel than the one that ran: traffic withheld"}
             return None, stale
         traffic, traffic_source = committed_traffic(kernel)
+
+        def valu_roof(kernel_name, launch_ms):
+            """The second roof (r05): VALU issue.  A wave64 f32 instruction issues every 2.05 cycles per SIMD when an even number of waves shares it (profiles/
+            r05_ubench_valu_issue.txt); frac = dynamic VALU wave-instructions per launch x 2.05 / (1024 SIMDs x the kernel's cycles at its in-kernel clock).  Instruction count
+            (rocprofv3 PMC SQ_INSTS_VALU) and in-kernel clock (s_memtime / s_memrealtime probe build) cannot be taken inside this process: they come from the committed
+            profiles/valu_<workload>[.fma].json, and only if that was measured on the kernel that ran here."""
+            for suffix in ("", ".fma"):
+                rel = "profiles/valu_%s%s.json" % (args.workload, suffix)
+                vpath = os.path.join(ROOT, rel)
+                if not os.path.exists(vpath):
+                    continue
+                try:
+                    rec = json.load(open(vpath))
+                except Exception:
+                    continue
+                if rec.get("kernel", "").split(" ")[0] != kernel_name.split(" ")[0]:
+                    continue
+                insts = rec["valu_insts_per_launch"] / rec.get("images_per_launch", 256) * n
+                cpi, ghz, simds = rec.get("cycles_per_inst", 2.05), rec["inkernel_ghz"], rec.get("simds", 1024)
+                issue_ms = insts * cpi / simds / (ghz * 1e6)
+                return {"bound": "valu-issue", "insts_per_launch": int(insts), "cycles_per_inst": cpi, "inkernel_ghz": ghz, "simds": simds,
+                        "issue_ms": round(issue_ms, 4), "frac": round(issue_ms / launch_ms, 4), "source": rel, "kernel": rec.get("kernel"), "round": rec.get("round")}
+            return None
+        valu = valu_roof(kernel, avg_launch_ms)
         out = {
             "metric": "Mpix/s batched 4K->1080p rgba cubic resize" if args.workload.startswith("cfg2") else "Mpix/s " + args.workload,
             "value": round(total_px / elapsed / 1e6, 1),
@@ -418,6 +442,9 @@ def main():
                 "ranks_seen": ranks_seen,
                 "per_rank_ms": [round(x, 3) for x in per_rank_ms],
                 "per_rank_device": per_rank_dev,
+                # where the two batches sit relative to each other (rank 0): destination placement moves cfg2 by up to 5.7 % (profiles/r04_placement.txt), so lines
+                # of different processes are comparable only with this beside them
+                "dst_minus_src_mb": (dst.tensor.data_ptr() - src.tensor.data_ptr()) >> 20,
             },
             "roofline": {
                 "bound": "hbm",
@@ -435,17 +462,24 @@ def main():
                 "max_launch_ms": round(sorted_ms[-1], 4),
                 "median_frac": round(alg_bytes / (median_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "read_only_frac": round(read_b / (avg_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                # what actually limits the kernel (measured, not part of the roofline definition of SURVEY.md 8d): profiles/r04_issue_models.txt
-                "note": ("fma flavour: at the time of its memory access pattern (profiles/r04_ubench_march_pattern.txt)" if numerics == "fma" else
-                         "bit-exact flavour: VALU-issue-bound where the source is 8-bit or the window long (issue time 80-120 % of the kernel time at the in-kernel "
-                         "clock, profiles/r04_issue_models.txt); cfg5 and the colour converts sit at their memory access pattern"),
+                # which of the two roofs (HBM here, VALU issue in roofline_valu) the launch is closer to
+                "tighter_roof": ("valu-issue" if valu and valu["frac"] > ach / HBM_PEAK_GBS else "hbm") if valu else None,
+                # what actually limits the kernel (measured, not part of the roofline definition of SURVEY.md 8d)
+                "note": ("cfg2: both flavours run at the time their loads + stores take without any arithmetic (fma 1.99 = 1.99 ms, bit-exact 2.19 vs 2.07-2.09 ms at its occupancy; "
+                         "arithmetic alone 1.12 / 1.52 ms): profiles/r05_ab_cfg2_ablate.txt.  In actual fabric bytes (1.17 x the algorithmic ones) the fma flavour moves 6.2 TB/s, the "
+                         "chip's measured copy rate.  VALU utilisation at 2.05 cycles per instruction is in roofline_valu (profiles/r05_issue_util.txt for the other workloads)"),
             },
         }
+        if valu:
+            out["roofline_valu"] = valu
         if other is not None:
             other["value_mpix_s"] = round(src_px / (other["avg_launch_ms"] * 1e-3) / 1e6, 1)
             other["roofline_frac"] = round(alg_bytes / (other["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             other["read_only_frac"] = round(read_b / (other["avg_launch_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
             other["traffic"], other["traffic_source"] = committed_traffic(other["kernel"])
+            ov = valu_roof(other["kernel"], other["avg_launch_ms"])
+            if ov:
+                other["roofline_valu"] = ov
             out["other_numerics"] = other
         if world == 1 and not args.no_cpu_baseline and not convert_to:
             out["cpu_baseline"] = cpu_baseline(args.workload)

@@ -94,8 +94,6 @@ long g_opt_work = 0;        // sym / accumulator kernels, work items: 0 auto, 1 
                             // 2 persistent launch (resident workgroups pull items from per-XCD atomic queues), 3 plain 3-D grid
 long g_opt_work_tail = 200; // per mille of every XCD's sub-list that is cut into short row chunks
 long g_opt_work_tail_div = 4;  // ... short chunk = long chunk / this
-long g_opt_work_order = 0;     // work-item lists: 0 = each XCD a contiguous eighth of the batch, 1 = (image, row chunk) units dealt round-robin, 2 = images dealt round-robin
-long g_opt_pw_grid = 0;        // persistent waves: per mille of the resident workgroups that are launched (0 = all: 1000)
 long g_opt_up = 0;          // integer upscales on the accumulator kernel (several outputs per lane, register accumulators): 0 auto (16-bit formats), 1 always, 2 never
 long g_opt_xch = 0;         // symmetric-table kernel, neighbour exchange (a lane loads only its own pixels): 0 auto, 1 wherever instantiated, 2 never
 
@@ -826,8 +824,7 @@ int sym_preferred_per_lane(int pixel, int step, int taps, int fma) {
 int get_items(DeviceCtx *ctx, int n, int dst_h, int nsb, int rows_long, int rows_short, int tail_pm, std::shared_ptr<const DeviceCtx::ItemList> *out) {
     std::shared_ptr<DeviceCtx::ItemList> evicted;   // released after `mu`: its hipFree synchronises the device
     std::unique_lock<std::mutex> lk(ctx->mu);
-    const int order = (int)std::max(0L, std::min(2L, g_opt_work_order));
-    auto key = std::make_tuple(n, dst_h, nsb, rows_long, rows_short, tail_pm + 10000 * order);
+    auto key = std::make_tuple(n, dst_h, nsb, rows_long, rows_short, tail_pm);
     auto it = ctx->item_lists.find(key);
     if (it != ctx->item_lists.end()) { it->second->used = ++ctx->use_tick; *out = it->second; return PICHA_OK; }
     if (ctx->item_lists.size() >= kMaxItemLists) {
@@ -845,20 +842,11 @@ int get_items(DeviceCtx *ctx, int n, int dst_h, int nsb, int rows_long, int rows
         for (int y = 0; y < dst_h; y += rl) units.push_back({i, y, std::min(dst_h, y + rl)});
     std::vector<int4> lists[8];
     const size_t U = units.size();
-    // which units an XCD works through, in order: a contiguous eighth (the chip's eight working sets are an eighth of the batch apart), or — measured
-    // alternatives, option "work_order" — every eighth unit / every eighth image (the chip's working set is ONE compact window of the batch)
-    std::vector<size_t> mine[8];
-    for (size_t k = 0; k < U; ++k) {
-        const int x = order == 1 ? (int)(k % 8) : order == 2 ? units[k].img % 8 : (int)std::min<size_t>(7, k * 8 / std::max<size_t>(1, U));
-        mine[x].push_back(k);
-    }
-    if (order == 0) for (int x = 0; x < 8; ++x) { mine[x].clear(); for (size_t k = U * x / 8; k < U * (x + 1) / 8; ++k) mine[x].push_back(k); }
     for (int x = 0; x < 8; ++x) {
-        const size_t lo = 0, hi = mine[x].size();
+        const size_t lo = U * x / 8, hi = U * (x + 1) / 8;
         const size_t tail = std::min<size_t>(hi - lo, ((hi - lo) * (size_t)tail_pm + 999) / 1000);
-        for (size_t kk = lo; kk < hi; ++kk) {
-            const size_t k = kk;
-            const Unit &u = units[mine[x][kk]];
+        for (size_t k = lo; k < hi; ++k) {
+            const Unit &u = units[k];
             const int step = (k >= hi - tail) ? std::max(1, rows_short) : (u.y1 - u.y0);
             // equal short chunks: ceil split
             const int pieces = (u.y1 - u.y0 + step - 1) / step;
@@ -1722,18 +1710,12 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 if (rc2) return rc2;
                 p.n_images = n;
                 p.work.items = il->items; p.work.items_per_xcd = il->per_xcd;
-                const bool pw = work_mode == 4 && !xch && !epi && sym_pw_supported(pixel, pl, sx, ax->host.taps, sy, ay->host.taps);
-                if (pw) p.work.wave_items = 1;   // persistent waves (r05): asked of the resident-blocks query too (its own instantiation)
-                if (work_mode == 2 || pw) {
+                if (work_mode == 2) {
                     const int resident = sym_kernel_resident_blocks(pixel, p);
-                    // (an explicit "work" = 4 takes the persistent grid at any size: the parity tests run it on small batches)
-                    if (resident > 0 && ((long long)il->per_xcd * 8 > 2LL * resident || (pw && opt_work == 4))) {
+                    if (resident > 0 && (long long)il->per_xcd * 8 > 2LL * resident) {
                         rc2 = get_queue(ctx, s, &p.work.queue, &qhold);
                         if (rc2) return rc2;
                         p.n_chunks = std::max(8, resident / 8 * 8);
-                        if (pw && g_opt_pw_grid > 0) p.n_chunks = std::max(8, (int)((long long)resident * std::min(1000L, g_opt_pw_grid) / 1000) / 8 * 8);
-                    } else {
-                        p.work.wave_items = 0;   // too short a launch for a persistent grid: one workgroup per item
                     }
                 }
                 const hipError_t e = launch_resize_sym_kernel(pixel, p, s, &g_last_kernel);
@@ -1796,8 +1778,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 // -3..5 %); the memory-bound fma flavour prefers 4 (neighbouring strips share their edge lines in one L1)
                 // (r03: with the explicit work-item list — every launch of >= 6144 waves — the reference arithmetic is as fast with
                 // 4 as with 2, 2.184 vs 2.186 ms on cfg2, and 4 keeps the fabric traffic at 1.09x instead of 1.14x: profiles/r03_ab_work_items.txt)
-                const bool big = (long long)n * ((cx->groups + 63) / 64) * std::max(1, d0.height / 60) >= 6144 && opt_work != 3;
-                const int bw = opt_bw > 0 ? (int)std::min<long>(opt_bw, 4) : (fma || big ? 4 : 2);
+                // (r05, one source / one destination, three devices: the reference arithmetic with the item list is 1.1-1.6 % faster with 1- or 2-wave groups than with 4 —
+                // 2.197 -> 2.163, 2.216 -> 2.191, 2.229 -> 2.213 ms on cfg2 — and the fma flavour 0.4-1.1 % slower: profiles/r05_ab_cfg2_misc.txt.  A 4-wave group needs four
+                // free slots on one CU at once; 25 % of the slot time of such a launch is spent waiting for that, profiles/r05_timeline.txt)
+                const int bw = opt_bw > 0 ? (int)std::min<long>(opt_bw, 4) : (fma ? 4 : 2);
                 if (epi && epi_used) *epi_used = true;
                 return launch_stream(pl, cx, cy, 0, false, true, bw, xch);
             }
@@ -2440,8 +2424,6 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "work") == 0) { g_opt_work = value; return PICHA_OK; }
     if (strcmp(key, "work_tail") == 0) { g_opt_work_tail = value; return PICHA_OK; }
     if (strcmp(key, "work_tail_div") == 0) { g_opt_work_tail_div = value; return PICHA_OK; }
-    if (strcmp(key, "pw_grid") == 0) { g_opt_pw_grid = value; return PICHA_OK; }
-    if (strcmp(key, "work_order") == 0) { g_opt_work_order = value; return PICHA_OK; }
     if (strcmp(key, "acc_p2") == 0) { g_opt_acc_p2 = value; return PICHA_OK; }
     if (strcmp(key, "long_block") == 0) { g_opt_long_block = value; return PICHA_OK; }
     if (strcmp(key, "xcd_remap") == 0) { g_opt_xcd_remap = value; return PICHA_OK; }
@@ -2476,8 +2458,6 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "work") == 0) return g_opt_work;
     if (strcmp(key, "work_tail") == 0) return g_opt_work_tail;
     if (strcmp(key, "work_tail_div") == 0) return g_opt_work_tail_div;
-    if (strcmp(key, "pw_grid") == 0) return g_opt_pw_grid;
-    if (strcmp(key, "work_order") == 0) return g_opt_work_order;
     if (strcmp(key, "acc_p2") == 0) return g_opt_acc_p2;
     if (strcmp(key, "long_block") == 0) return g_opt_long_block;
     if (strcmp(key, "xcd_remap") == 0) return g_opt_xcd_remap;

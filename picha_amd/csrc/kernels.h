@@ -42,10 +42,6 @@ struct WorkList {
     const int4 *items = nullptr;   // {strip block, y0, y1, image}; y0 == y1: padding
     int items_per_xcd = 0;
     unsigned *queue = nullptr;     // [8]
-    // r05, resize_sym_kernel: persistent WAVES — every wave takes (item, strip of the item's block) pairs from its XCD's sub-list by itself, one
-    // returning atomic per pair, requested while the previous pair is still marching (its latency is never exposed); no barrier, no LDS hand-off;
-    // queue[x] then counts pairs (items_per_xcd * waves per workgroup of them)
-    int wave_items = 0;
 };
 
 // ---- resize: two-pass kernels through an HBM scratch (any geometry) ---------------------------
@@ -204,7 +200,6 @@ hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStre
 bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty);
 bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int xch = 0);
 bool sym_epi_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty);   // colour-convert epilogue instantiation
-bool sym_pw_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty);    // persistent-wave instantiation (WorkList::wave_items)
 hipError_t launch_resize_sym_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
 // workgroups of the persistent form the device holds at once for the configuration in p (0: no such instantiation)
 int sym_kernel_resident_blocks(int pixel, const StreamParams &p);

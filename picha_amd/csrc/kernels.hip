@@ -26,7 +26,6 @@ PICHA_DECL_STREAM(4) PICHA_DECL_STREAM(5) PICHA_DECL_STREAM(6) PICHA_DECL_STREAM
 #define PICHA_DECL_SYM(N)                                                                \
     bool sym_supported_pixel##N(int per_lane, int sx, int tx, int sy, int ty, int xch);   \
     bool sym_epi_supported_pixel##N(int per_lane, int sx, int tx, int sy, int ty);        \
-    bool sym_pw_supported_pixel##N(int per_lane, int sx, int tx, int sy, int ty);         \
     hipError_t launch_sym_pixel##N(const StreamParams &p, hipStream_t s, const char **name); \
     int sym_resident_pixel##N(const StreamParams &p);
 PICHA_DECL_SYM(0) PICHA_DECL_SYM(1) PICHA_DECL_SYM(2) PICHA_DECL_SYM(3)
@@ -102,14 +101,6 @@ int run_kernel_resident_blocks(int pixel, const RunParams &p) {
 bool sym_epi_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty) {
     switch (pixel) {
 #define PICHA_CASE(N) case N: return sym_epi_supported_pixel##N(per_lane, sx, tx, sy, ty);
-    PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
-#undef PICHA_CASE
-    }
-    return false;
-}
-bool sym_pw_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty) {
-    switch (pixel) {
-#define PICHA_CASE(N) case N: return sym_pw_supported_pixel##N(per_lane, sx, tx, sy, ty);
     PICHA_CASE(0) PICHA_CASE(1) PICHA_CASE(2) PICHA_CASE(3) PICHA_CASE(4) PICHA_CASE(5) PICHA_CASE(6) PICHA_CASE(7)
 #undef PICHA_CASE
     }

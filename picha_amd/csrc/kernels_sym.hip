@@ -23,9 +23,10 @@ namespace picha_hip {
 namespace {
 
 template <int N> using IC = std::integral_constant<int, N>;
-// Measurement builds only (scripts/r04_build_variant.sh; results differ from the reference — never shipped):
+// Measurement builds only (scripts/build_variant.sh; results differ from the reference — never shipped; profiles/r05_ab_cfg2_ablate.txt):
 //   -DPICHA_SYM_ABLATE=1  no destination stores (and no pack)     =2  no source loads inside the march (it computes on the rows of the prologue)
 //   -DPICHA_SYM_ABLATE=3  loads and stores only: the arithmetic of a row is one XOR over its registers
+//   any non-zero value also reads PICHA_SYM_LDS (environment): bytes of unused dynamic LDS per workgroup, which holds a build at a chosen number of waves per SIMD
 #ifndef PICHA_SYM_ABLATE
 #define PICHA_SYM_ABLATE 0
 #endif
@@ -33,18 +34,13 @@ constexpr int ce_min(int a, int b) { return a < b ? a : b; }
 
 // NBUF row buffers in registers (NBUF - 1 rows in flight per wave): 3 unless a row is more than 12 dwords per lane
 template <int CH, bool S16, int P, int SX, int TX, bool XCH> constexpr int sym_nbuf() {
-#ifdef PICHA_SYM_NBUF   // measurement builds: deeper row prefetch (6 = five rows in flight per wave; the unrolled group stays three steps)
-    return PICHA_SYM_NBUF;
-#endif
     return (XCH ? XchCfg<CH, S16, P, SX, TX>::NOWN + XchCfg<CH, S16, P, SX, TX>::NE : SpanCfg<CH, S16, P, SX, TX>::NW) <= 12 ? 3 : 2;
 }
 
 // EPI (r04): the colour convert of a resize -> colorConvert chain as a STORE EPILOGUE (as on the accumulator kernel since r03,
 // epilogue_store in kernels_impl.inc): the finished pixel is packed to the resize's own sample type exactly as src/resize.cc:130
 // writes it, unpacked, channel-mapped and packed to p.epi_pixel (src/colorconvert.cc:143-150); dst_* describe THAT image.
-// PW (r05): persistent waves — the kernel takes (item, strip) pairs per WAVE from the work list (run_wave_items); its own instantiation so that the
-// register allocation of the list / grid forms stays what it was
-template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA, bool XCH = false, bool EPI = false, bool PW = false>
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA, bool XCH = false, bool EPI = false>
 __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
     using C = SpanCfg<CH, S16, P, SX, TX>;
     using X = XchCfg<CH, S16, P, SX, TX>;
@@ -59,8 +55,8 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    auto run_item = [&](int bx, int y0, int y1, int img, int wv) __attribute__((always_inline)) {
-    const int grp0 = (bx * (blockDim.x >> 6) + wv) * kWave;  // 1..4 waves per workgroup (host's choice); wv: which strip of the block this wave marches
+    auto run_item = [&](int bx, int y0, int y1, int img) __attribute__((always_inline)) {
+    const int grp0 = (bx * (blockDim.x >> 6) + wave) * kWave;  // 1..4 waves per workgroup (host's choice)
     if (grp0 * P >= p.dst_w) return;  // wave-uniform; the march has no barriers
     const int x0 = (grp0 + lane) * P;
 
@@ -91,9 +87,6 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
 #pragma unroll
             for (int id = 0; id < TXH; ++id) asm volatile("v_mov_b32 %0, %1" : "=v"(wx[0][id]) : "s"(p.x_canon[id]));
             lane_off = (SX * x0 + p.x_base) * C::BPP + sadj;
-#ifdef PICHA_SYM_ALIGN_TEST   // measurement builds only (results shifted): every wave's window starts this many bytes later — what would line-aligned windows buy?
-            lane_off += PICHA_SYM_ALIGN_TEST;
-#endif
         } else {
             const int grp = min(grp0 + lane, p.x_groups - 1);
 #pragma unroll
@@ -138,31 +131,11 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
             }
         };
 
-#ifdef PICHA_SYM_PREFETCH_REC
-        int wbn[YW];
-#pragma unroll
-        for (int t = 0; t < YW; ++t) wbn[t] = ystep[(size_t)y0 * YW + t];
-#endif
         auto one_step = [&](int m, auto k_c) __attribute__((always_inline)) {
             constexpr int K = decltype(k_c)::value;
             int wb[YW];
-#ifdef PICHA_SYM_PREFETCH_REC
-            // the step record was requested one step ago: its scalar-cache latency is not exposed at the top of the step
-#pragma unroll
-            for (int t = 0; t < YW; ++t) wb[t] = wbn[t];
-            {
-                // scalar loads return out of order, so the only wait is lgkmcnt(0): take it HERE (this step's record left a step ago and has
-                // arrived), before the next record's loads are issued — otherwise the first use of wb[] would wait for those too
-#pragma unroll
-                for (int t = 0; t < YW; ++t) asm volatile("" ::"s"(wb[t]) : "memory");
-                const int mn = min(m + 1, m_end);
-#pragma unroll
-                for (int t = 0; t < YW; ++t) wbn[t] = ystep[(size_t)mn * YW + t];
-            }
-#else
 #pragma unroll
             for (int t = 0; t < YW; ++t) wb[t] = ystep[(size_t)m * YW + t];
-#endif
             const bool ycanon = (wb[YW - 1] & 2) != 0;  // all NPEND outputs of this step exist and are canonical
             // optional: keep the waves of a workgroup (adjacent column strips) on the same step, so the partial lines at
             // their common edge are fetched once and hit in the CU's L1 (waves that left the kernel do not take part)
@@ -173,24 +146,16 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
                 const int bi = T % NB;                     // buffer holding this row
                 const int bn = (T + NB - 1) % NB;          // buffer consumed by the previous row: refill it, NB-1 rows ahead
                 const int row = SY * m + p.y_base + ph;
-#ifdef PICHA_SYM_PRIO_LOADS   // measurement builds: the wave's priority raised while it computes the addresses of and issues the next row's loads
-                __builtin_amdgcn_s_setprio(PICHA_SYM_PRIO_LOADS);
-#endif
                 if (PICHA_SYM_ABLATE != 2 || p.src_h < 0) load_row(raw[bn], row + NB - 1);
-#ifdef PICHA_SYM_PRIO_LOADS
-                __builtin_amdgcn_s_setprio(0);
-#endif
 #if PICHA_SYM_ABLATE == 3
                 {
-                    // xacc runs over ALL rows: a per-row value would be dead on the rows that complete no output, and the compiler then deletes
-                    // their loads (r05 call 1 measured exactly that: "7.7 TB/s")
+                    // xacc runs over ALL rows: a per-row value would be dead on the rows that complete no output, and the compiler then deletes their loads
 #pragma unroll
                     for (int k = 0; k < NRAW; ++k) xacc ^= raw[bi][k];
-                    const uint32_t x = xacc;
                     if (ph == PHCLOSE && m - ICLOSE >= y0 && x0 + P <= p.dst_w) {
                         uint32_t dw[P * C::BPP / 4];
 #pragma unroll
-                        for (int k = 0; k < P * C::BPP / 4; ++k) dw[k] = x + k;
+                        for (int k = 0; k < P * C::BPP / 4; ++k) dw[k] = xacc + k;
                         store_dwords<P * C::BPP / 4, kStoreNT>(dst_rs, uint32_t((m - ICLOSE) * p.dst_stride + x0 * C::BPP), dw);
                     }
                     continue;
@@ -291,59 +256,39 @@ __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
     if (interior) march(std::true_type{}, IC<NBUF>{});
     else march(std::false_type{}, IC<(NBUF > 2 ? NBUF - 1 : 2)>{});
     };  // run_item
-    if constexpr (PW) {
-#ifdef PICHA_PW_PRIO   // measurement builds: persistent waves all have the same age, so the issue arbiter ("priority, then age") has no order among them and they march in step;
-        // give the waves of a SIMD distinct static priorities by their slot number
-        switch (__builtin_amdgcn_s_getreg((31 << 11) | 4) & 3u) {
-            case 1: __builtin_amdgcn_s_setprio(1); break;
-            case 2: __builtin_amdgcn_s_setprio(2); break;
-            case 3: __builtin_amdgcn_s_setprio(3); break;
-            default: break;
-        }
-#endif
-#ifdef PICHA_PW_STAGGER   // measurement builds: do persistent waves that all start at once march in lockstep (all waiting, then all computing)?  A pseudo-random start delay of 0 .. 60 us per wave
-        {
-            const unsigned h = ((blockIdx.x * (blockDim.x >> 6) + wave) * 2654435761u) >> 28;   // 0 .. 15
-            for (unsigned i = 0; i < h; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-#endif
-        run_wave_items(p.work, run_item);
-    } else {
-        run_work_items(p.work, [&](int &ibx, int &y0, int &y1, int &img) __attribute__((always_inline)) {
-            unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
-            if (p.xcd_remap) xcd_contiguous_block(bx, by, bz);
-            ibx = int(bx); y0 = int(by) * p.rows_per_chunk; y1 = min(p.dst_h, y0 + p.rows_per_chunk); img = int(bz);
-        }, [&](int bx, int y0, int y1, int img) __attribute__((always_inline)) { run_item(bx, y0, y1, img, wave); });
-    }
+    run_work_items(p.work, [&](int &ibx, int &y0, int &y1, int &img) __attribute__((always_inline)) {
+        unsigned bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+        if (p.xcd_remap) xcd_contiguous_block(bx, by, bz);
+        ibx = int(bx); y0 = int(by) * p.rows_per_chunk; y1 = min(p.dst_h, y0 + p.rows_per_chunk); img = int(bz);
+    }, run_item);
     PICHA_PROBE_END
 }
 
-template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool XCH = false, bool EPI = false, bool PW = false>
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool XCH = false, bool EPI = false>
 hipError_t launch_sym_t(const StreamParams &p, hipStream_t s, const char **name) {
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 2;
     dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
     if (p.work.items) grid = dim3(p.work.queue ? (unsigned)p.n_chunks : 8u * (unsigned)p.work.items_per_xcd, 1, 1);  // persistent: n_chunks = resident workgroups
-    if (PW && (!p.work.items || !p.work.queue || !p.work.wave_items)) return hipErrorInvalidValue;
     size_t lds = 0;
-#if PICHA_SYM_ABLATE   // measurement builds: PICHA_SYM_LDS = bytes of (unused) dynamic LDS per workgroup, to hold an ablated kernel at the shipped kernel's waves per SIMD
+#if PICHA_SYM_ABLATE
     if (const char *e = getenv("PICHA_SYM_LDS")) lds = (size_t)atol(e);
 #endif
-    if (p.fma) resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true, XCH, EPI, PW><<<grid, 64 * bw, lds, s>>>(p);
-    else resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false, XCH, EPI, PW><<<grid, 64 * bw, lds, s>>>(p);
+    if (p.fma) resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true, XCH, EPI><<<grid, 64 * bw, lds, s>>>(p);
+    else resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false, XCH, EPI><<<grid, 64 * bw, lds, s>>>(p);
     char epi[40] = "";
     if (EPI) snprintf(epi, sizeof epi, ",epilogue -> %s", kPixelNameAll[p.epi_pixel & 7]);
     snprintf(g_kernel_name, sizeof g_kernel_name, "resize_sym<ch%d,%s,P%d,SX%d,TX%d,SY%d,TY%d,%s,bw%d%s%s%s>", CH, S16 ? "u16" : "u8", P, SX, TX, SY,
-             TY, p.fma ? "fma" : "exact", bw, XCH ? ",xch" : "", epi, p.work.wave_items ? ",wave-items" : p.work.queue ? ",persistent" : p.work.items ? ",items" : "");
+             TY, p.fma ? "fma" : "exact", bw, XCH ? ",xch" : "", epi, p.work.queue ? ",persistent" : p.work.items ? ",items" : "");
     if (name) *name = g_kernel_name;
     return hipGetLastError();
 }
 
-template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool XCH = false, bool PW = false>
+template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool XCH = false>
 int sym_resident_t(const StreamParams &p) {
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 2;
     int per_cu = 0, dev = 0, cus = 0;
-    const void *k = p.fma ? reinterpret_cast<const void *>(resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true, XCH, false, PW>)
-                          : reinterpret_cast<const void *>(resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false, XCH, false, PW>);
+    const void *k = p.fma ? reinterpret_cast<const void *>(resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, true, XCH>)
+                          : reinterpret_cast<const void *>(resize_sym_kernel<CH, S16, P, SX, TX, SY, TY, false, XCH>);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * bw, 0) != hipSuccess) return 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     return per_cu * cus;
@@ -356,12 +301,8 @@ int sym_resident_t(const StreamParams &p) {
 // symmetric): 2x: 3 (triangle), 5 (default options), 7 (cubic / mitchel / catmulrom); 3x: 8, 12; 4x: 11, 15.  lanczos and
 // box at even integer scales alias the reference's ring (src/resize.cc:52-64) and stay on the span kernel.
 #define PICHA_SYM_LIST_0(X) /* rgb */ X(4, 2, 5, 2, 5) X(4, 3, 8, 3, 8) X(4, 4, 11, 4, 11) X(4, 4, 15, 4, 15)
-#if PICHA_SYM_ABLATE == 3   // loads + stores only: what do wider strips per wave (5 / 6 / 10 / 15 outputs per lane) do to the memory pattern's time?
-#define PICHA_SYM_LIST_1(X) /* rgba */ X(2, 2, 5, 2, 5) X(3, 2, 5, 2, 5) X(4, 2, 5, 2, 5) X(5, 2, 5, 2, 5) X(6, 2, 5, 2, 5) X(10, 2, 5, 2, 5) X(15, 2, 5, 2, 5)
-#else
 #define PICHA_SYM_LIST_1(X) /* rgba */ X(2, 2, 5, 2, 5) X(3, 2, 5, 2, 5) X(4, 2, 5, 2, 5) X(2, 2, 7, 2, 7) X(3, 2, 7, 2, 7) \
     X(2, 3, 8, 3, 8) X(2, 4, 11, 4, 11) X(2, 4, 15, 4, 15)
-#endif
 #define PICHA_SYM_LIST_2(X) /* grey */ X(4, 2, 5, 2, 5) X(4, 2, 7, 2, 7)
 #define PICHA_SYM_LIST_3(X) /* greya */ X(2, 2, 3, 2, 3) X(4, 2, 5, 2, 5) X(4, 2, 7, 2, 7) X(2, 3, 8, 3, 8) X(2, 3, 12, 3, 12)
 #define PICHA_SYM_LIST_4(X) /* r16 */ X(2, 2, 3, 2, 3) X(4, 2, 3, 2, 3) X(4, 2, 5, 2, 5) X(4, 2, 7, 2, 7) X(2, 3, 8, 3, 8) \
@@ -395,16 +336,6 @@ int sym_resident_t(const StreamParams &p) {
 #define PICHA_SYME_LIST_6(E)
 #define PICHA_SYME_LIST_7(E) /* r16g16b16a16 */ E(2, 2, 5, 2, 5)
 
-// Persistent-wave instantiations: W(P, SX, TX, SY, TY) — the shapes whose launches are long enough for it to matter and where it measured ahead (r05)
-#define PICHA_SYMW_LIST_0(W)
-#define PICHA_SYMW_LIST_1(W) /* rgba */ W(3, 2, 5, 2, 5)
-#define PICHA_SYMW_LIST_2(W)
-#define PICHA_SYMW_LIST_3(W)
-#define PICHA_SYMW_LIST_4(W)
-#define PICHA_SYMW_LIST_5(W)
-#define PICHA_SYMW_LIST_6(W)
-#define PICHA_SYMW_LIST_7(W)
-
 }  // namespace
 
 #ifndef PICHA_SYM_PIXEL
@@ -415,14 +346,6 @@ int sym_resident_t(const StreamParams &p) {
 #define PICHA_SYM_LIST PICHA_CAT(PICHA_SYM_LIST_, PICHA_SYM_PIXEL)
 #define PICHA_SYMX_LIST PICHA_CAT(PICHA_SYMX_LIST_, PICHA_SYM_PIXEL)
 #define PICHA_SYME_LIST PICHA_CAT(PICHA_SYME_LIST_, PICHA_SYM_PIXEL)
-#define PICHA_SYMW_LIST PICHA_CAT(PICHA_SYMW_LIST_, PICHA_SYM_PIXEL)
-
-bool PICHA_CAT(sym_pw_supported_pixel, PICHA_SYM_PIXEL)(int per_lane, int sx, int tx, int sy, int ty) {
-#define W(P, SX, TX, SY, TY) if (per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY) return true;
-    PICHA_SYMW_LIST(W)
-#undef W
-    return false;
-}
 
 bool PICHA_CAT(sym_epi_supported_pixel, PICHA_SYM_PIXEL)(int per_lane, int sx, int tx, int sy, int ty) {
 #define E(P, SX, TX, SY, TY) if (per_lane == P && sx == SX && tx == TX && sy == SY && ty == TY) return true;
@@ -444,11 +367,6 @@ bool PICHA_CAT(sym_supported_pixel, PICHA_SYM_PIXEL)(int per_lane, int sx, int t
 }
 
 int PICHA_CAT(sym_resident_pixel, PICHA_SYM_PIXEL)(const StreamParams &p) {
-#define W(P, SX, TX, SY, TY)                                                                                          \
-    if (p.work.wave_items && !p.xch && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY) \
-        return sym_resident_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY, false, true>(p);
-    PICHA_SYMW_LIST(W)
-#undef W
 #define Y(P, SX, TX, SY, TY)                                                                                          \
     if (p.xch && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY)           \
         return sym_resident_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY, true>(p);
@@ -470,12 +388,6 @@ hipError_t PICHA_CAT(launch_sym_pixel, PICHA_SYM_PIXEL)(const StreamParams &p, h
     PICHA_SYME_LIST(E)
 #undef E
     if (p.epi_on) return hipErrorInvalidValue;
-#define W(P, SX, TX, SY, TY)                                                                                          \
-    if (p.work.wave_items && !p.xch && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY) \
-        return launch_sym_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY, false, false, true>(p, s, name);
-    PICHA_SYMW_LIST(W)
-#undef W
-    if (p.work.wave_items) return hipErrorInvalidValue;
 #define Y(P, SX, TX, SY, TY)                                                                                          \
     if (p.xch && p.x_per_lane == P && p.x_step == SX && p.x_taps == TX && p.y_step == SY && p.y_taps == TY)           \
         return launch_sym_t<pixel_channels(PICHA_SYM_PIXEL), pixel_is16(PICHA_SYM_PIXEL), P, SX, TX, SY, TY, true>(p, s, name);

@@ -2,7 +2,7 @@
 (-DPICHA_CLOCK_PROBE, scripts/build_variant.sh) stamps s_memtime / s_memrealtime at the start and end of every wave;
 clock = sum(d memtime) / sum(d memrealtime) x 100 MHz, read after >= 2 s of back-to-back launches on random pixels.
 
-usage: PICHA_HIP_LIB=picha_amd/variants/libpicha_hip_probe.so python scripts/r04_clock_probe.py
+usage: PICHA_HIP_LIB=picha_amd/variants/libpicha_hip_probe.so python scripts/clock_probe.py [label substring ...]
 """
 import ctypes
 import sys
@@ -35,7 +35,10 @@ def main():
     lib = N.lib()
     torch.cuda.set_device(0)
     print("library: %s" % N.SO_PATH)
+    only = sys.argv[1:]   # optional: label substrings (e.g. "cfg2" "cfg5")
     for label, n, pixel, sw, sh, dw, dh, popt, lopt, sym in CASES:
+        if only and not any(o in label for o in only):
+            continue
         try:
             probe = getattr(lib, sym)
         except AttributeError:

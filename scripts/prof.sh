@@ -17,7 +17,9 @@ for set in \
   "SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS SQ_THREAD_CYCLES_VALU SQ_INSTS_VALU_CVT SQ_INSTS_VALU_MUL_F32 SQ_INSTS_VALU_ADD_F32 SQ_INSTS_VALU_FMA_F32" \
   "FETCH_SIZE" "WRITE_SIZE" \
   "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_EA0_RDREQ_sum" \
-  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" ; do
+  "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum" \
+  "TCC_EA0_RDREQ_128B_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_LEVEL_sum TCC_EA0_WRREQ_64B_sum" \
+  "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_LEVEL_sum TCC_EA0_WRREQ_STALL_sum" ; do   # r05: the memory-side requests by size and target (DRAM-typed vs all; no MALL counter exists)
   i=$((i+1))
   echo "[prof] pass $i: $set"
   timeout -k 10 240 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $out/pmc$i -- python3 $root/bench.py $args > $out/pmc$i.log 2>&1 || echo "pass $i failed" >> $out/fail.txt

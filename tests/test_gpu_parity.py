@@ -1027,47 +1027,6 @@ def test_persistent_launch_covers_every_item_of_a_long_list():
     assert len(set.union(*sums.values())) == 1, sums
 
 
-@pytest.mark.parametrize("bw", [1, 2, 4])
-def test_persistent_waves_match_oracle(bw):
-    """r05: the symmetric-table kernel as PERSISTENT WAVES ("work" = 4): every wave takes (item, strip) pairs from the per-XCD lists by itself, the next
-    pair's atomic in flight while it marches.  Batches shorter and longer than the resident grid, ragged last strips (a width that leaves waves of a block
-    without columns), short chunks, 1 / 2 / 4 waves per workgroup, both flavours: every image equals the oracle (fma: within 1), and a second launch on the
-    same stream (the counters are zeroed per launch) gives the same bytes."""
-    from picha_amd.device import DeviceBatch, resize_batch
-    import torch
-    try:
-        for n, sw, sh, dw, dh, chunks in [(5, 1152, 640, 576, 320, 6), (40, 1152, 320, 576, 160, 4), (3, 2600, 120, 1300, 60, 2), (64, 1152, 640, 576, 320, 9)]:
-            src = DeviceBatch(n, sw, sh, "rgba").fill_random(31 + n)
-            for numerics in (0, 1):
-                set_opt("numerics", numerics)
-                set_opt("work", 4)
-                set_opt("block_waves", bw)
-                set_opt("row_chunks", chunks)
-                out = DeviceBatch(n, dw, dh, "rgba")
-                out.tensor.zero_()   # the pitch padding behind an image is never written: same bytes in every run compared below
-                out = resize_batch(src, dw, dh, out=out)
-                torch.cuda.synchronize()
-                name = N.lib().picha_hip_last_kernel().decode()
-                assert name.endswith(",wave-items>") and ("bw%d" % bw) in name, name
-                first = out.tensor.clone()
-                for i in range(0, n, max(1, n // 7)):
-                    exp = oracle_resize(src.image_host(i), dw, dh, "cubic", 0.70)
-                    d = np.abs(out.image_host(i).pixels().astype(np.int64) - exp.pixels().astype(np.int64)).max()
-                    assert d <= numerics, (name, i, d)
-                out.tensor.zero_()
-                out = resize_batch(src, dw, dh, out=out)
-                torch.cuda.synchronize()
-                assert torch.equal(out.tensor, first), name
-                set_opt("work", 1)   # ... and the item-list form writes the same bytes
-                out.tensor.zero_()
-                out = resize_batch(src, dw, dh, out=out)
-                torch.cuda.synchronize()
-                assert torch.equal(out.tensor, first), (name, N.lib().picha_hip_last_kernel().decode())
-    finally:
-        for k in ("work", "block_waves", "row_chunks", "numerics"):
-            set_opt(k, 0)
-
-
 @pytest.mark.parametrize("pixel", ["rgb", "grey", "greya", "rgba", "r16", "r16g16b16"])
 @pytest.mark.parametrize("filt", [None, "cubic", "triangle", "mitchel"])
 def test_integer_upscales_on_the_accumulator_kernel_match_oracle(pixel, filt):
