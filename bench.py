@@ -37,7 +37,7 @@ WORKLOADS = {
     # intermediate is materialised slice by slice
     "cfg3_4k_rgb_to_grey_to_512_lanczos_chained": (256, 3840, 2160, "rgb", 512, 512, {"convert": "grey", "filter": "lanczos", "chain": True}),
     "cc_4k_rgba_to_rgba16": (64, 3840, 2160, "rgba", 3840, 2160, {"convert": "r16g16b16a16"}),
-    # codec-edge pairs (reference index.js:37-72 supportedMap x the codecs' `encodes` lists, README.md:158-159,
+    # codec-edge pairs (LAB.md 6.3; reference index.js:37-72 supportedMap x the codecs' `encodes` lists, README.md:158-159,
     # src/pngcodec.cc:61-86): what toSupported() converts before a jpeg / webp encode and what decoders hand to resize
     "edge_jpeg_4k_rgba_to_rgb": (128, 3840, 2160, "rgba", 3840, 2160, {"convert": "rgb"}),              # tiff/png/webp decode -> jpeg encode
     "edge_jpeg_4k_rgba16_to_rgb": (64, 3840, 2160, "r16g16b16a16", 3840, 2160, {"convert": "rgb"}),      # deep png -> jpeg

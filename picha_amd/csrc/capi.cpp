@@ -1240,7 +1240,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     }
     chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, opt_chunks > 0 ? d0.height : d0.height / 16)));
     if (opt_chunks <= 0 && xhl >= 0 && p.phase_shift > 0) {
-        // the neighbour-exchange form with phased stores is bound by its memory pattern: every halo row it re-reads is
+        // the neighbour-exchange form with phased stores is bound by its memory pattern (LAB.md 5.0c): every halo row it re-reads is
         // time.  Longer chunks — halo under ~3 % — as long as the launch stays at least two rounds of resident workgroups
         // (cfg5, 32 images: 18 -> 12 chunks 1.922 -> 1.892 ms, fma 1.781 -> 1.732; 9 chunks = 1.4 rounds 2.012; profiles/r04_ab_run_xch.txt)
         const double src_rows_per_out = std::max(1.0, (double)s0.height / d0.height);

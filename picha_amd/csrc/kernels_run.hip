@@ -17,7 +17,7 @@
 // The few columns whose windows are clipped by an image edge (renormalised weights: 4 of 512 for cfg3b) come out of the march
 // with the canonical weights and are then OVERWRITTEN by resize_edges_kernel (same stream, launched after it): the reference's
 // double sum with those columns' own weights, from a stash of raw pixels that the two lanes holding such columns leave behind
-// (edge_pass below; how the other forms of this step measured: profiles/r03_ab_run_kernel.txt).
+// (edge_pass below; how the other forms of this step measured: profiles/r03_ab_run_kernel.txt, LAB.md 5.4b).
 #define PICHA_SPAN_ONLY 1
 #include "kernels_impl.inc"
 #include <cstring>
@@ -912,7 +912,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 #define PICHA_UP_LIST_7(U) /* r16g16b16a16 */ U(1, 2, 9, 2, 0, 8, 9)   /* upscales: four outputs per lane measured 13 % slower than the accumulator form (0.49 against 0.56) */
 
 // Convert-in-front instantiations of the ring kernel (r04): V(SRCP, Q, PX, TX, P, RC, K, TYM) under the DESTINATION format's translation unit — the codec-edge
-// pairs of DESIGN.md 6.3 (-> jpeg: rgb / grey; -> webp: rgb / rgba; deep png -> 8 bit) at 2x with picha's defaults (3 taps, offsets rounded up) and at 4x.
+// pairs of LAB.md 6.3 (-> jpeg: rgb / grey; -> webp: rgb / rgba; deep png -> 8 bit) at 2x with picha's defaults (3 taps, offsets rounded up) and at 4x.
 #define PICHA_UPCV_LIST_0(V) /* -> rgb */ V(1, 2, 1, 3, 4, 1, 4, 4) V(2, 2, 1, 3, 4, 1, 4, 4) V(6, 2, 1, 3, 4, 1, 4, 4) V(7, 2, 1, 3, 4, 1, 4, 4) \
     V(1, 4, 1, 4, 8, 0, 4, 4) V(2, 4, 1, 4, 8, 0, 4, 4)
 #define PICHA_UPCV_LIST_1(V) /* -> rgba */ V(0, 2, 1, 3, 4, 1, 4, 4) V(3, 2, 1, 3, 4, 1, 4, 4) V(7, 2, 1, 3, 4, 1, 4, 4) \
