@@ -326,6 +326,15 @@ int picha_hip_image_copy_device(int n, const picha_image *src, const picha_image
 /* ---- device memory helpers for hosts without an allocator of their own (Node addon, C tests) --- */
 int picha_hip_malloc(void **dev_ptr, size_t bytes);
 int picha_hip_free(void *dev_ptr);
+/*
+ * A destination arena at a MEASURED placement (r05).  How long a resize takes depends on where its destination sits in HBM relative to its source — by 3-7 % between
+ * buffers allocated one after the other, the first one after the source being the slowest in every record (profiles/r04_placement.txt, r05_placement.txt) — and nothing in the
+ * addresses predicts it.  A service allocates its output arena once: this call allocates `candidates` (1..16) buffers of `bytes`, times picha.resize of the n device images
+ * src[] into dst[] laid out in each of them (dst[i].data on entry = the byte OFFSET of image i inside the arena), keeps the fastest, frees the others, and returns its base in
+ * *dev_ptr with dst[i].data rewritten to absolute device pointers.  ms_out (may be NULL): candidates floats, the time per launch measured into each (the kept one is the
+ * minimum).  Synchronous; release with picha_hip_free.  The reference has no analogue: its destination is whatever `new Buffer` returned (src/resize.cc:293-300).
+ */
+int picha_hip_malloc_placed(void **dev_ptr, size_t bytes, int n, const picha_image *src, picha_image *dst, int filter, float filter_scale, int candidates, float *ms_out);
 int picha_hip_memcpy_h2d(void *dev_dst, const void *host_src, size_t bytes, void *stream);
 int picha_hip_memcpy_d2h(void *host_dst, const void *dev_src, size_t bytes, void *stream);
 int picha_hip_stream_synchronize(void *stream);

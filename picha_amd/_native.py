@@ -89,6 +89,7 @@ SYMBOLS = [
     ("picha_hip_image_copy_device", _i, [_i, _P, _P, _vp]),
     ("picha_hip_malloc", _i, [ctypes.POINTER(_vp), _sz]),
     ("picha_hip_free", _i, [_vp]),
+    ("picha_hip_malloc_placed", _i, [ctypes.POINTER(_vp), _sz, _i, _P, _P, _i, _f, _i, ctypes.POINTER(_f)]),
     ("picha_hip_memcpy_h2d", _i, [_vp, _vp, _sz, _vp]),
     ("picha_hip_memcpy_d2h", _i, [_vp, _vp, _sz, _vp]),
     ("picha_hip_stream_synchronize", _i, [_vp]),

@@ -976,6 +976,8 @@ bool run_xch_preferred(int pixel, int period_px, int taps, int per_lane, int fma
     return pixel == PICHA_R16G16B16A16 || (pixel == PICHA_RGBA && fma);
 }
 
+// PICHA_HIP_TRACE_PLAN=1: why run_group left a geometry to the other kernels (the line of the rule that declined it)
+#define RUN_GROUP_NA do { static const bool trace_na = getenv("PICHA_HIP_TRACE_PLAN") != nullptr; if (trace_na) fprintf(stderr, "picha_hip: run_group declines at capi.cpp:%d\n", __LINE__); return PICHA_OK; } while (0)
 // Run kernel for one equal-geometry group: downscales whose x scale is a ratio of small integers with a long window.
 // *used = false: not applicable, the caller goes on with the other kernels.
 // cv != nullptr (r04): src[] are in another pixel format than dst[] — picha.colorConvert to dst[].pixel, then picha.resize, as ONE kernel: integer
@@ -994,24 +996,24 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
         opt_bw = g_opt_block_waves;
     }
-    if (opt_run == 2 || ((s0.pixel != d0.pixel) != (cv != nullptr))) return PICHA_OK;
+    if (opt_run == 2 || ((s0.pixel != d0.pixel) != (cv != nullptr))) RUN_GROUP_NA;
     // downscales (the march + per-source-row records), or upscales by an integer factor in x (resize_up_kernel: register ring in y)
     const bool up = d0.width > s0.width && d0.height > s0.height;
-    if (!up && (cv || d0.width >= s0.width || d0.height >= s0.height)) return PICHA_OK;
-    if (up && (d0.width % s0.width != 0 || d0.width / s0.width > 4)) return PICHA_OK;
+    if (!up && (cv || d0.width >= s0.width || d0.height >= s0.height)) RUN_GROUP_NA;
+    if (up && (d0.width % s0.width != 0 || d0.width / s0.width > 4)) RUN_GROUP_NA;
     const size_t src_span = image_span(s0), dst_span = image_span(d0);
-    if (src_span >= (1u << 30) || dst_span >= (1u << 30)) return PICHA_OK;
+    if (src_span >= (1u << 30) || dst_span >= (1u << 30)) RUN_GROUP_NA;
     const int al = fused_align(spixel);
     for (int i = 0; i < n; ++i) {
-        if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) return PICHA_OK;
-        if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % 4) return PICHA_OK;  // a lane stores its run as whole dwords
-        if (src[i].stride % 4) return PICHA_OK;  // the edge pass fetches a block of rows at one byte phase
+        if (((uintptr_t)src[i].data | (uintptr_t)src[i].stride) % al) RUN_GROUP_NA;
+        if (((uintptr_t)dst[i].data | (uintptr_t)dst[i].stride) % 4) RUN_GROUP_NA;  // a lane stores its run as whole dwords
+        if (src[i].stride % 4) RUN_GROUP_NA;  // the edge pass fetches a block of rows at one byte phase
     }
     // the period: scale = period_px / period in lowest terms
     int g = s0.width, b = d0.width;
     while (b) { const int t = g % b; g = b; b = t; }
     const int period = d0.width / g, period_px = s0.width / g;
-    if (period > 4) return PICHA_OK;
+    if (period > 4) RUN_GROUP_NA;
     std::shared_ptr<DeviceAxis> ax_ref, ay_ref;
     int rc = get_axis(ctx, filter, fscale, s0.width, d0.width, &ax_ref);
     if (rc) return rc;
@@ -1048,7 +1050,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
                     }
                 }
         }
-        if (!any) return PICHA_OK;
+        if (!any) RUN_GROUP_NA;
     }
     if (!up) {
         for (int na : {4, 6}) {
@@ -1066,10 +1068,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
                 if (ty.eff[(size_t)y * ty.taps + j] != ty.left[y] + j) { aliased = true; break; }
         if (up) ring_rows = 4;
         else if (ty.ref_ring == 8 || ty.ref_ring == 16) ring_rows = ty.ref_ring;
-        else return PICHA_OK;
-        if (!(ring_rows == ty.ref_ring || (!aliased && ty.span <= ring_rows)) || ty.taps > ring_rows + 1) return PICHA_OK;
+        else RUN_GROUP_NA;
+        if (!(ring_rows == ty.ref_ring || (!aliased && ty.span <= ring_rows)) || ty.taps > ring_rows + 1) RUN_GROUP_NA;
         for (int y = 1; y < d0.height; ++y)
-            if (ty.need[y] < ty.need[y - 1]) return PICHA_OK;   // rows are emitted in order
+            if (ty.need[y] < ty.need[y - 1]) RUN_GROUP_NA;   // rows are emitted in order
         rc = get_yrange(ctx, ay, &up_range);
         if (rc) return rc;
     }
@@ -1079,10 +1081,13 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // profiles/r03_survey_run_kernel.txt)
     int tx_of[2], xb_unused = 0;
     for (int c = 0; c < 2; ++c) tx_of[c] = run_table_taps(ax->host, period, period_px, c, &xb_unused);
-    if (tx_of[0] <= 0) return PICHA_OK;
-    static const int order1[] = {4, 8, 2}, order2[] = {2, 4, 8};
+    if (tx_of[0] <= 0) RUN_GROUP_NA;
+    static const int order1[] = {4, 8, 2, 0, 0, 0}, order2[] = {2, 4, 8, 0, 0, 0};   // (0: no candidate)
     // upscales (r03, profiles/r03_ab_up_kernel.txt): the longest run that is instantiated
-    static const int order_up[] = {8, 4, 2};
+    // (3x upscales were instantiated in r05 — runs of 3 / 6 / 12 — and the run table declines them: the reference accumulates its tap centres in binary32
+    //  (src/resize.cc:23-26, center += scale) and 1/3 is not a binary fraction, so beyond narrow rows output x + 3 does NOT carry output x's weights bit for
+    //  bit; only the factors 2 and 4 are periodic.  3x stays on the lane-resident-weight kernels: 0.32-0.40 of the roof at 64 images, profiles/r05_ab_up3.txt)
+    static const int order_up[] = {8, 4, 2, 0, 0, 0};
     // neighbour-exchange form (r04): dword-sized pixels at integer scales; the canonical window starts -x_base pixels before the
     // lane's own; the clipped columns are recomputed from the image (no stash)
     int xhl = -1;
@@ -1103,12 +1108,12 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         for (int tx = tx_of[c]; tx <= tx_of[c] + 3 && !per_lane; ++tx)
             for (int pl0 : (up || (period == 2 && period_px == 3) ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
                 const int pl = opt_per_lane > 0 ? (int)opt_per_lane : pl0;   // "per_lane" names the run length outright
-                if (pl % period || !(cv ? up_cv_kernel_supported(pixel, spixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : (run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c) || (opt_run_ws != 2 && run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c, -1, 1))))) continue;
+                if (pl <= 0 || pl % period || !(cv ? up_cv_kernel_supported(pixel, spixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : (run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c) || (opt_run_ws != 2 && run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c, -1, 1))))) continue;
                 per_lane = pl; ktaps = tx; ceil_off = c;
                 break;
             }
     }
-    if (!per_lane) return PICHA_OK;
+    if (!per_lane) RUN_GROUP_NA;
     // where it is the default (same survey): windows of 26 taps and more (cfg3b: -3 % reference arithmetic, -10 % fma against the
     // row-staged kernel; greya -35 %); shorter windows only for batches that still fill the chip with a quarter of the
     // accumulator kernel's waves (256 x 4K -> 512x288 grey: -11 %; 128 images: a tie; integer scales 6x / 8x: -9 .. -13 % at 128 images)
@@ -1116,27 +1121,27 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // measured on 128-256 images); the 21-tap 7.5x shape was a tie for greya and needs >= 192 images for grey
     const int ch = kChannels[pixel];
     const bool short_ok = period_px == 15 ? (ch == 1 && n >= 192) : (ch <= 2 && n >= 96);
-    if (!ring_mode && xhl < 0 && opt_run == 0 && ktaps < 26 && !short_ok) return PICHA_OK;
+    if (!ring_mode && xhl < 0 && opt_run == 0 && ktaps < 26 && !short_ok) RUN_GROUP_NA;
     // one phase's weights in SGPRs (r04): where instantiated — the 7.5x shapes, whose 2 x 30 lane-uniform weight registers held the
     // kernel at 3 waves per SIMD (profiles/r04_ab_run_ws.txt)
     const int wsgpr = !ring_mode && xhl < 0 && opt_run_ws != 2 && run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -1, 1) ? 1 : 0;
     const DeviceAxis::RunTable *rt = nullptr;
     rc = get_runtable(ctx, ax, period, period_px, ceil_off, ktaps, wmode, is16, &rt);
     if (rc) return rc;
-    if (!rt->ok) return PICHA_OK;
+    if (!rt->ok) RUN_GROUP_NA;
 
     // edge columns: recomputed by resize_edges_kernel from a stash of the raw dwords of the two lanes that hold them (kernels_run.hip)
     const int x_groups = (d0.width + per_lane - 1) / per_lane;
     const bool has_edges = rt->c0 > 0 || rt->c1 < d0.width;
-    if (xhl >= 0 && rt->x_base != -xhl) return PICHA_OK;
+    if (xhl >= 0 && rt->x_base != -xhl) RUN_GROUP_NA;
     int stash_words = 0, stash_org[2] = {0, 0};
     if (has_edges && xhl < 0 && !cv) {
         const int bpp = kBytes[pixel];
         const int span = ((per_lane - 1) / period) * period_px + (((per_lane - 1) % period) * period_px + ceil_off * (period - 1)) / period + ktaps;  // RunCfg::SPAN
         stash_words = bpp % 4 == 0 ? span * bpp / 4 : (span * bpp + 3) / 4 + 1;                                        // RunCfg::NW
-        if (x_groups < 2) return PICHA_OK;
+        if (x_groups < 2) RUN_GROUP_NA;
         for (int i = 0; i < n; ++i)
-            if ((uintptr_t)src[i].data % 4) return PICHA_OK;  // the stash is laid out for lane windows that start on a dword of the row
+            if ((uintptr_t)src[i].data % 4) RUN_GROUP_NA;  // the stash is laid out for lane windows that start on a dword of the row
         const int g_last = (d0.width - 1) / per_lane;
         for (int side = 0; side < 2; ++side) {
             const int g = side == 0 ? 0 : g_last;
@@ -1144,10 +1149,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
             const int org = (ws * bpp) & ~3;
             stash_org[side] = org;
             const int xa = side == 0 ? 0 : rt->c1, xb = side == 0 ? rt->c0 : d0.width;
-            if (side == 0 ? rt->c0 > per_lane : rt->c1 < g_last * per_lane) return PICHA_OK;   // the side's columns all belong to that lane
+            if (side == 0 ? rt->c0 > per_lane : rt->c1 < g_last * per_lane) RUN_GROUP_NA;   // the side's columns all belong to that lane
             for (int x = xa; x < xb; ++x) {
                 const int bo = ax->host.left[x] * bpp - org;
-                if (bo < 0 || bo + ax->host.count[x] * bpp > stash_words * 4) return PICHA_OK;
+                if (bo < 0 || bo + ax->host.count[x] * bpp > stash_words * 4) RUN_GROUP_NA;
             }
         }
     }
@@ -1171,7 +1176,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         int er = std::min(64, d0.height);
         auto floats = [&](int rows) { return ncol * txe + rows * ty.taps + ncol * ch * max_rows(rows); };
         while (er > 1 && floats(er) > 2048) --er;
-        if (floats(er) > 2048) return PICHA_OK;
+        if (floats(er) > 2048) RUN_GROUP_NA;
         edge_rows = er;
     }
     RunParams p{};
@@ -1199,7 +1204,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     if (cv) { p.cv_on = 1; p.cv_src_pixel = spixel; p.cv_r = cv->r; p.cv_g = cv->g; p.cv_b = cv->b; }
     if (has_edges && opt_run != 3 && xhl < 0 && !cv) {
         const size_t bytes = (size_t)n * 2 * s0.height * stash_words * 4;
-        if (bytes >= ((size_t)1 << 32)) { (void)release_temps(); return PICHA_OK; }
+        if (bytes >= ((size_t)1 << 32)) { (void)release_temps(); RUN_GROUP_NA; }
         if (!temp_lock.owns_lock()) temp_lock.lock();
         rc = temp_acquire(ctx->scratch, bytes, 0, s);
         if (rc) { (void)release_temps(); return rc; }
@@ -2784,6 +2789,53 @@ int picha_hip_malloc(void **dev_ptr, size_t bytes) {
 }
 int picha_hip_free(void *dev_ptr) {
     HIP_TRY(hipFree(dev_ptr));
+    return PICHA_OK;
+}
+int picha_hip_malloc_placed(void **dev_ptr, size_t bytes, int n, const picha_image *src, picha_image *dst, int filter, float filter_scale, int candidates, float *ms_out) {
+    if (!dev_ptr || !src || !dst || n <= 0 || bytes == 0 || candidates < 1 || candidates > 16) return fail(PICHA_ERR_ARGUMENT, "bad arguments");
+    *dev_ptr = nullptr;
+    int dev;
+    int rc = current_device(&dev);
+    if (rc) return rc;
+    std::vector<void *> base((size_t)candidates, nullptr);
+    std::vector<size_t> off((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        off[(size_t)i] = (size_t)(uintptr_t)dst[i].data;
+        const size_t need = off[(size_t)i] + (dst[i].height > 0 ? image_span(dst[i]) : 0);
+        if (need > bytes) return fail(PICHA_ERR_ARGUMENT, "destination image outside the arena");
+    }
+    auto free_all = [&](int keep) { for (int c = 0; c < candidates; ++c) if (c != keep && base[(size_t)c]) (void)hipFree(base[(size_t)c]); };
+    for (int c = 0; c < candidates; ++c)   // all alive at once: each lands somewhere else
+        if (hipMalloc(&base[(size_t)c], bytes) != hipSuccess) { free_all(-1); return fail(PICHA_ERR_HIP, "arena allocation failed"); }
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    auto cleanup = [&]() { if (e0) (void)hipEventDestroy(e0); if (e1) (void)hipEventDestroy(e1); if (s) (void)hipStreamDestroy(s); };
+    if (hipStreamCreate(&s) != hipSuccess || hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { cleanup(); free_all(-1); return fail(PICHA_ERR_HIP, "stream / event creation failed"); }
+    std::vector<picha_image> d(dst, dst + n);
+    std::vector<float> best((size_t)candidates, 3.4e38f);
+    const int launches = 6;
+    for (int round = 0; round < 3 && rc == PICHA_OK; ++round)   // round 0 builds the tables and raises the clocks; two interleaved timed rounds decide
+        for (int c = 0; c < candidates && rc == PICHA_OK; ++c) {
+            for (int i = 0; i < n; ++i) d[(size_t)i].data = static_cast<uint8_t *>(base[(size_t)c]) + off[(size_t)i];
+            rc = picha_hip_resize_device(n, src, d.data(), filter, filter_scale, s);
+            if (rc || round == 0) continue;
+            (void)hipEventRecord(e0, s);
+            for (int k = 0; k < launches && rc == PICHA_OK; ++k) rc = picha_hip_resize_device(n, src, d.data(), filter, filter_scale, s);
+            (void)hipEventRecord(e1, s);
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(PICHA_ERR_HIP, "placement timing failed"); break; }
+            float ms = 0.0f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            best[(size_t)c] = std::min(best[(size_t)c], ms / launches);
+        }
+    (void)hipStreamSynchronize(s);
+    cleanup();
+    if (rc) { free_all(-1); return rc; }
+    int keep = 0;
+    for (int c = 1; c < candidates; ++c) if (best[(size_t)c] < best[(size_t)keep]) keep = c;
+    free_all(keep);
+    for (int i = 0; i < n; ++i) dst[i].data = static_cast<uint8_t *>(base[(size_t)keep]) + off[(size_t)i];
+    if (ms_out) for (int c = 0; c < candidates; ++c) ms_out[c] = candidates == 1 ? 0.0f : best[(size_t)c];
+    *dev_ptr = base[(size_t)keep];
     return PICHA_OK;
 }
 int picha_hip_memcpy_h2d(void *d, const void *h, size_t bytes, void *stream) {

@@ -192,3 +192,36 @@ class ResizePlan:
         rc = self._fn(self.src.n, self._s, self._d, self.ftag, self.fscale, st)
         if rc:
             N.check(rc)
+
+
+def place_destination(make_dst, make_plan, src, candidates=4, launches=6):
+    """Choose where a destination batch lives by measurement (r05).
+
+    The time of a launch depends on where its destination sits in HBM relative to its source — by 3-7 % between buffers allocated one after the other
+    (profiles/r04_placement.txt, profiles/r05_placement.txt); nothing in the address predicts it, so a caller that allocates its output arena once can try a few:
+    `candidates` batches from make_dst() are all allocated (so each lands somewhere else), make_plan(dst).run() is timed into each, the fastest is kept and the
+    others are freed.  Returns (dst, plan, record) — record = {"candidates": [[offset from src in MB, ms per launch], ...], "kept": index}."""
+    dsts = [make_dst() for _ in range(max(1, candidates))]
+    plans = [make_plan(d) for d in dsts]
+    if len(dsts) == 1:
+        return dsts[0], plans[0], {"candidates": [[(dsts[0].tensor.data_ptr() - src.tensor.data_ptr()) >> 20, None]], "kept": 0}
+    for p in plans:      # tables built, clocks up
+        p.run()
+    torch.cuda.synchronize(src.tensor.device)
+    best = [float("inf")] * len(plans)
+    for _ in range(2):   # two interleaved rounds: a slow first round (clock ramp) cannot decide
+        for i, p in enumerate(plans):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            p.run()
+            e0.record()
+            for _ in range(launches):
+                p.run()
+            e1.record()
+            torch.cuda.synchronize(src.tensor.device)
+            best[i] = min(best[i], e0.elapsed_time(e1) / launches)
+    kept = min(range(len(plans)), key=lambda i: best[i])
+    record = {"candidates": [[(d.tensor.data_ptr() - src.tensor.data_ptr()) >> 20, round(ms, 4)] for d, ms in zip(dsts, best)], "kept": kept}
+    dst, plan = dsts[kept], plans[kept]
+    del dsts, plans
+    torch.cuda.empty_cache()
+    return dst, plan, record

@@ -34,6 +34,10 @@ CASES = {
     "lanczos8x": (64, "rgb", 3840, 2160, 480, 270, "lanczos", None),
     "jpegthumb": (192, "rgb", 3840, 2160, 512, 288, None, None),
 }
+# colorConvert + resize as one call (picha_hip_convert_resize_device, convert first): case -> (resize case fields..., destination pixel)
+CHAINED = {
+    "cfg3": (256, "rgb", 3840, 2160, 512, 512, "lanczos", None, "grey"),
+}
 
 
 def load(path):
@@ -57,7 +61,10 @@ def main():
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("variants", nargs="+")
     a = ap.parse_args()
-    if a.case in CASES:
+    convert_to = None
+    if a.case in CHAINED:
+        n, pixel, sw, sh, dw, dh, filt, fscale, convert_to = CHAINED[a.case]
+    elif a.case in CASES:
         n, pixel, sw, sh, dw, dh, filt, fscale = CASES[a.case]
     else:
         f = a.case.split(":")
@@ -84,8 +91,10 @@ def main():
         opts = dict(kv.split("=") for kv in optstr.split(",") if kv)
         variants.append((name, libs[path], {k: int(x) for k, x in opts.items()}, os.path.basename(path)))   # UPPER-CASE keys are environment variables of measurement builds
     src = DeviceBatch(n, sw, sh, pixel).fill_random(20250226)
-    dst = DeviceBatch(n, dw, dh, pixel)
+    dst = DeviceBatch(n, dw, dh, convert_to or pixel)
     sd, dd = src.descriptors(), dst.descriptors()
+    from picha_amd.api import color_settings
+    cr, cg, cb = color_settings()
     stream = torch.cuda.current_stream().cuda_stream
     print("# %s: %d x %dx%d %s -> %dx%d filter %s; ONE source at 0x%x, ONE destination at 0x%x (offset %+d MB); %d rounds x %d launches, %s numerics"
           % (a.case, n, sw, sh, pixel, dw, dh, filt or "default", src.tensor.data_ptr(), dst.tensor.data_ptr(),
@@ -112,7 +121,10 @@ def main():
                 raise SystemExit("option %s=%d refused by %s" % (k, x, L._name))
 
     def run(L):
-        rc = L.picha_hip_resize_device(n, sd, dd, ftag, fs, stream)
+        if convert_to:
+            rc = L.picha_hip_convert_resize_device(n, sd, dd, 0, cr, cg, cb, ftag, fs, stream)
+        else:
+            rc = L.picha_hip_resize_device(n, sd, dd, ftag, fs, stream)
         if rc:
             raise SystemExit("resize failed: %s" % L.picha_hip_last_error().decode())
 
@@ -141,8 +153,12 @@ def main():
                     if not a.no_oracle:
                         diffs = []
                         for i in (0, n - 1):
-                            e, _ = oracle.resize(src.image_host(i).data, sw, sh, pixel, dw, dh, filt or "cubic", fs)
-                            exp = picha_amd.Image(width=dw, height=dh, pixel=pixel, data=e).pixels().astype(np.int64)
+                            if convert_to:
+                                mid, _ = oracle.color_convert(src.image_host(i).data, sw, sh, pixel, convert_to)
+                                e, _ = oracle.resize(mid, sw, sh, convert_to, dw, dh, filt or "cubic", fs)
+                            else:
+                                e, _ = oracle.resize(src.image_host(i).data, sw, sh, pixel, dw, dh, filt or "cubic", fs)
+                            exp = picha_amd.Image(width=dw, height=dh, pixel=convert_to or pixel, data=e).pixels().astype(np.int64)
                             diffs.append(int(np.abs(dst.image_host(i).pixels().astype(np.int64) - exp).max()))
                         par[name] = "oracle diff %d (images 0, %d)" % (max(diffs), n - 1)
                     else:

@@ -1170,3 +1170,36 @@ def test_work_item_lists_survive_eviction_under_concurrent_callers():
         assert not errors, errors[:5]
     finally:
         set_opt("work", 0)
+
+
+def test_destination_arena_at_a_measured_placement():
+    """r05: picha_hip_malloc_placed allocates several destination arenas, times the resize into each, keeps the fastest and frees the others; the images it returns hold
+    the resize's output (last timed launch), bit-exact against the oracle; bad arguments are refused."""
+    import torch
+    from picha_amd.device import DeviceBatch, row_stride
+    n, sw, sh, dw, dh = 6, 640, 480, 320, 240
+    src = DeviceBatch(n, sw, sh, "rgba").fill_random(77)
+    stride = row_stride(dw, "rgba")
+    pitch = (dh * stride + 255) // 256 * 256
+    dst = (N.CImage * n)()
+    for i in range(n):
+        dst[i] = N.CImage(i * pitch, stride, dw, dh, N.pixel_index("rgba"))   # data = offset inside the arena
+    base = ctypes.c_void_p()
+    ms = (ctypes.c_float * 3)()
+    from picha_amd.api import _resize_options
+    ftag, fscale = _resize_options({})
+    N.check(N.lib().picha_hip_malloc_placed(ctypes.byref(base), n * pitch, n, src.descriptors(), dst, ftag, fscale, 3, ms))
+    try:
+        assert base.value and all(m > 0 for m in ms) and dst[0].data == base.value and dst[n - 1].data == base.value + (n - 1) * pitch
+        host = np.empty(n * pitch, dtype=np.uint8)
+        N.check(N.lib().picha_hip_memcpy_d2h(host.ctypes.data, base, n * pitch, None))
+        N.check(N.lib().picha_hip_stream_synchronize(None))
+        for i in range(n):
+            exp = oracle_resize(src.image_host(i), dw, dh, "cubic", 0.70)
+            got = picha_amd.Image(width=dw, height=dh, pixel="rgba", stride=stride, data=host[i * pitch:i * pitch + dh * stride].copy())
+            assert np.array_equal(got.pixels(), exp.pixels()), i
+    finally:
+        N.check(N.lib().picha_hip_free(base))
+    dst[0] = N.CImage(n * pitch, stride, dw, dh, N.pixel_index("rgba"))   # an image that does not fit the arena
+    assert N.lib().picha_hip_malloc_placed(ctypes.byref(base), n * pitch, n, src.descriptors(), dst, ftag, fscale, 2, None) != 0
+    assert N.lib().picha_hip_malloc_placed(ctypes.byref(base), n * pitch, n, src.descriptors(), dst, ftag, fscale, 0, None) != 0
