@@ -156,8 +156,8 @@ def spawn_ranks(n, argv):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)   # 50 x 2 ms: a 100 ms timed region (r04 review: 44 ms was thin beside a 5.7 % placement effect)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", default="cfg2_4k_rgba_to_1080p_cubic", choices=sorted(WORKLOADS) + ["custom"])
     ap.add_argument("--shape", default="", help="with --workload custom: n:pixel:src_w:src_h:dst_w:dst_h[:filter[:filterScale]]")
     ap.add_argument("--images", type=int, default=0, help="override images per GPU")
