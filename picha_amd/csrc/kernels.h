@@ -152,8 +152,8 @@ constexpr bool span_rotate(int bytes_per_pixel, int x_taps_bucket) {
 // must be scaled by 2^22).  Measured r01 (profiles/r01_ab_denorm_unpack.txt): 16-bit samples −5.5 % kernel time (one
 // v_mul_f32_sdwa instead of and/shift + cvt + mul), grey −3 %; 8-bit multi-channel formats are 4–10 % SLOWER that
 // way (their v_cvt_f32_ubyteN overlaps with the multiply/add stream, an SDWA multiply does not), so they keep cvt + mul.
-// (r04: 8-bit grey left this set.  An SDWA instruction costs the issue of three or four plain ones (profiles/r04_ubench_valu_rates.txt: one v_mul_f32_sdwa among
-//  three multiply-adds slows the stream from 2.45 to 4.0 cycles per instruction) while v_cvt_f32_ubyteN overlaps with the multiply-add pipe: cvt + mul measured
+// (r04: 8-bit grey left this set.  An SDWA instruction costs the issue of three or four plain ones (profiles/r05_ubench_valu_issue.txt: any v_mul_f32_sdwa
+//  in a multiply-add stream puts it at 4.0 cycles per instruction instead of 2.05) while v_cvt_f32_ubyteN overlaps with the multiply-add pipe: cvt + mul measured
 //  -2.5 .. -7 % on the grey downscales (profiles/r04_ab_unpack_forms.txt).  16-bit samples keep the denormal form: and / shift + cvt + mul is 9 % slower on cfg5.)
 constexpr bool exact_unpack_scaled(int channels, bool is16) { (void)channels; return is16; }
 int fused_y_pad(int y_taps);

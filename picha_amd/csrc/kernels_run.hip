@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void resize_edges_kernel(RunParams p) {
 // handed to the two edge lanes through 256 bytes of wave-private LDS when the row is resampled.  The columns an image edge clips
 // come out with the canonical weights here and are overwritten by resize_edges_kernel reading the IMAGE (no stash: p.edge_image).
 // WS (r04): the weights of the last WS phases of the period stay in SGPRs (alone an SGPR-operand product issues at half rate, inside a multiply-add
-// stream it costs the same slot as any other: profiles/r04_ubench_valu_rates.txt; Q x TX lane-uniform VGPRs are what kept cfg3b at 3 waves per SIMD).
+// stream it costs the same slot as any other: profiles/r05_ubench_valu_issue.txt; Q x TX lane-uniform VGPRs are what kept cfg3b at 3 waves per SIMD).
 template <int CH, bool S16, int Q, int PX, int TX, int P, int XHL> struct RunXch {
     static constexpr int BPP = CH * Sample<S16>::kBytes;
     static constexpr int DPX = BPP / 4;

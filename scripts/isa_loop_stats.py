@@ -1,14 +1,14 @@
 """Instruction mix of a kernel's hot loop from the shipped code object: finds the largest backward-branch region of a kernel, counts
-instructions by class (with the issue cost per class measured in profiles/r04_ubench_valu_rates.txt: every plain instruction one slot of 2.45 cycles inside a
-multiply-add stream, SDWA / DPP / packed-f32 forms ~8.7 because they stall it), lists the waits and nops.  STATIC counts: code of both sides of a branch is counted.
+instructions by class (issue cost per class from profiles/r05_ubench_valu_issue.txt: every plain instruction one slot of 2.05 cycles inside a
+multiply-add stream at an even number of co-resident waves; a stream that contains SDWA / DPP / packed-f32 forms issues at 4.0 as a whole — shown as a flag, not priced per instruction), lists the waits and nops.  STATIC counts: code of both sides of a branch is counted.
 
 usage: python scripts/isa_loop_stats.py <libpicha_hip.so | object file> <substring of the mangled kernel name> [rows per iteration]
 """
 import collections, os, re, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
-# issue cycles per wave-instruction per SIMD (r04_ubench_valu_rates.txt; the r01 table this script first used was low by 1.8 x)
-COST = {"v_mul_f32": 2.45, "v_add_f32": 2.45, "v_fma_f32": 2.45, "v_fmac_f32": 2.45, "v_mul_f32 (sgpr operand)": 2.45, "v_fma_f32 (sgpr operand)": 2.45,
-        "sdwa": 8.7, "dpp": 8.7, "v_cvt": 2.45, "v_med3": 2.45, "v_alignbyte": 2.45, "v_mov": 2.45, "v_int": 2.45, "v_other": 2.45}
+# issue cycles per wave-instruction per SIMD (r05_ubench_valu_issue.txt)
+COST = {"v_mul_f32": 2.05, "v_add_f32": 2.05, "v_fma_f32": 2.05, "v_fmac_f32": 2.05, "v_mul_f32 (sgpr operand)": 2.05, "v_fma_f32 (sgpr operand)": 2.05,
+        "sdwa": 2.05, "dpp": 2.05, "v_cvt": 2.05, "v_med3": 2.05, "v_alignbyte": 2.05, "v_mov": 2.05, "v_int": 2.05, "v_other": 2.05}
 
 
 def classify(op, rest):
@@ -84,7 +84,9 @@ def main():
         cycles += t
         print("  %-28s %5d per iteration  %7.1f per row%s" % (k, cnt[k], cnt[k] / rows, "   x %.2f cycles = %7.1f per row" % (c, t / rows) if c else ""))
     nvalu = sum(v for k, v in cnt.items() if k in COST)
-    print("  VALU instructions per row: %.1f; issue cycles per row at the measured per-class rates: %.1f" % (nvalu / rows, cycles / rows))
+    half = cnt.get("sdwa", 0) + cnt.get("dpp", 0)
+    print("  VALU instructions per row: %.1f; issue cycles per row at 2.05 per instruction: %.1f%s" % (nvalu / rows, cycles / rows,
+          "  — the stream contains %d SDWA / DPP instructions: it issues at 4.0 per instruction as a whole (%.1f per row)" % (half, 4.0 * nvalu / rows) if half else ""))
     waits = [(a, rest) for a, op, rest in body if op.startswith("s_waitcnt")]
     print("  s_waitcnt in the loop (%d):" % len(waits), ", ".join(r for _, r in waits))
     nops = [rest for _, op, rest in body if op.startswith("s_nop")]
