@@ -1692,8 +1692,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 // resize_sym_kernel (r02, profiles/r02_ab_sym_*.txt): waves that live for ~60 output rows (reference arithmetic)
                 // or ~20 (fma flavour, memory-bound) keep the chip's working set compact and its tail short; the TY - SY halo
                 // rows a chunk re-filters cost less than that gains while the halo stays under ~8 % of the chunk
+                // (r05, one source / one destination: the fma flavour gains another 1.1-1.8 % from 12- to 16-row chunks although they re-read 17-25 % more halo
+                // rows — short-lived workgroups in address order are what its memory pattern wants; profiles/r05_ab_cfg2_misc.txt, last section)
                 const int halo = std::max(0, ay->host.taps - sy);
-                const int rows = std::max(fma ? 20 : 60, (halo * 12 + sy - 1) / sy);
+                const int rows = fma ? std::max(12, (halo * 8 + sy - 1) / sy) : std::max(60, (halo * 12 + sy - 1) / sy);
                 chunks = std::max<long long>(chunks, (d0.height + rows - 1) / rows);
             }
             chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, opt_chunks > 0 ? d0.height : d0.height / 16)));

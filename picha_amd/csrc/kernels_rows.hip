@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(RowsParams p) {
     float *lds = reinterpret_cast<float *>(lds_raw);
     const int buf_floats = KST * 256 * FW;          // one row buffer
 
+    PICHA_PROBE_BEGIN
     const int t = threadIdx.x;
     const int strip = blockIdx.x;
     const int img = blockIdx.z;
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(256) void resize_rows_kernel(RowsParams p) {
         };
         run(run, IC<0>{});
     }
+    PICHA_PROBE_END
 }
 
 template <int SCH, bool SS16, int CH, bool S16, int P, int S, int TXB, int KST, int NACC>
@@ -352,6 +354,7 @@ hipError_t launch_rows_shape(const RowsParams &p, hipStream_t s, const char **na
 #endif
 #define PICHA_CAT2(a, b) a##b
 #define PICHA_CAT(a, b) PICHA_CAT2(a, b)
+PICHA_PROBE_HOST(PICHA_CAT(picha_probe_rows_v, PICHA_ROWS_VARIANT))
 bool PICHA_CAT(rows_supported_variant, PICHA_ROWS_VARIANT)(int per_lane, int step, int taps) { return rows_shape_supported<ROWS_T>(per_lane, step, taps); }
 hipError_t PICHA_CAT(launch_rows_variant, PICHA_ROWS_VARIANT)(const RowsParams &p, hipStream_t s, const char **name) {
     return launch_rows_shape<ROWS_T>(p, s, name);

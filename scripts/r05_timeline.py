@@ -24,6 +24,11 @@ CASES = {
     "cfg2fma": (256, "rgba", 3840, 2160, 1920, 1080, {}, {"numerics": 1}, "picha_probe_sym_p1"),
     "cfg5": (32, "r16g16b16a16", 7680, 4320, 1920, 1080, {"filter": "mitchel"}, {}, "picha_probe_run_p7"),
     "cfg3b": (256, "grey", 3840, 2160, 512, 512, {"filter": "lanczos"}, {}, "picha_probe_run_p2"),
+    # colorConvert + resize as one call (the fused row-staged kernel): popt carries the destination format
+    "cfg3": (256, "rgb", 3840, 2160, 512, 512, {"filter": "lanczos", "convert": "grey"}, {}, "picha_probe_rows_v2"),
+    "lanczos2x": (64, "rgba", 3840, 2160, 1920, 1080, {"filter": "lanczos"}, {}, "picha_probe_run_p1"),
+    "lanczos8x": (64, "rgb", 3840, 2160, 480, 270, {"filter": "lanczos"}, {}, "picha_probe_span_p0"),
+    "jpegthumb": (192, "rgb", 3840, 2160, 512, 288, {}, {}, "picha_probe_span_p0"),
 }
 SLOTS = 1 << 18
 
@@ -127,8 +132,16 @@ def main():
         for k, v in lopt.items():
             N.check(lib.picha_hip_set_option(k.encode(), v))
         src = DeviceBatch(n, sw, sh, pixel).fill_random(1)
-        dst = DeviceBatch(n, dw, dh, pixel)
-        plan = ResizePlan(src, dst, filter=popt.get("filter"), filter_scale=popt.get("filterScale"))
+        dst = DeviceBatch(n, dw, dh, popt.get("convert", pixel))
+        if popt.get("convert"):
+            from picha_amd.device import convert_resize_batch
+
+            class _Chain:
+                def run(self):
+                    convert_resize_batch(src, popt["convert"], dw, dh, filter=popt.get("filter"), out=dst)
+            plan = _Chain()
+        else:
+            plan = ResizePlan(src, dst, filter=popt.get("filter"), filter_scale=popt.get("filterScale"))
         plan.run()
         torch.cuda.synchronize()
         name = lib.picha_hip_last_kernel().decode()
