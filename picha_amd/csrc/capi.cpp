@@ -1788,7 +1788,10 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 // (r05, one source / one destination, three devices: the reference arithmetic with the item list is 1.1-1.6 % faster with 1- or 2-wave groups than with 4 —
                 // 2.197 -> 2.163, 2.216 -> 2.191, 2.229 -> 2.213 ms on cfg2 — and the fma flavour 0.4-1.1 % slower: profiles/r05_ab_cfg2_misc.txt.  A 4-wave group needs four
                 // free slots on one CU at once; 25 % of the slot time of such a launch is spent waiting for that, profiles/r05_timeline.txt)
-                const int bw = opt_bw > 0 ? (int)std::min<long>(opt_bw, 4) : (fma ? 4 : 2);
+                // ... for 8-bit formats: -3 .. -5 % at 3x (greya, rgba); the 16-bit formats at 2x (r16g16, r16g16b16, r16g16b16a16: twice the bytes per output, nearer their
+                // memory pattern) keep 4 on launches that go through the item list: -1.5 .. -1.7 % (profiles/r05_ab_cfg2_misc.txt, last section)
+                const bool big = (long long)n * ((cx->groups + 63) / 64) * std::max(1, d0.height / 60) >= 6144 && opt_work != 3;
+                const int bw = opt_bw > 0 ? (int)std::min<long>(opt_bw, 4) : (fma || (is16 && big) ? 4 : 2);
                 if (epi && epi_used) *epi_used = true;
                 return launch_stream(pl, cx, cy, 0, false, true, bw, xch);
             }
