@@ -964,6 +964,13 @@ long g_opt_run = 0;   // run kernel (periodic tap tables, kernels_run.hip): 0 au
 long g_opt_run_round = 0;  // its window offsets inside a period: 0 auto (the shorter window), 1 rounded down, 2 rounded up
 long g_opt_run_xch = 0;    // its neighbour-exchange form (dword-sized pixels, integer scales; r04): 0 auto, 1 wherever instantiated, 2 never
 long g_opt_run_ws = 0;     // weights of one phase of the period in SGPRs (r04): 0 auto, 1 wherever instantiated, 2 never
+long g_opt_run_shu = 0;    // shared unpack through LDS (r05; 8-bit grey / greya, kernels_run.hip RunShu): 0 auto (wherever instantiated), 1 the same, 2 never
+long g_opt_run_edges = 0;  // where resize_edges_kernel takes the clipped columns' windows from (it follows the march on the same stream either way): 0 auto, 1 a stash the march
+                           // writes (r03 form; the image where the form has no stash), 2 the image.  Auto = the measured winner (profiles/r05_ab_run_edges_shu.txt): the
+                           // stash for the plain grey run kernel only (-1.3 .. -1.9 % against the image); greya, the ring / upscale kernels and the shared-unpack form read
+                           // the image (greya 7.5x -5 %, rgba 2x upscale -4 %, grey lanczos 2x -2.6 %: their stash rows are longer than the lines the image costs).
+                           // (r05, measured and removed: the edge kernel on a second stream BESIDE a march that leaves those columns alone — +5 .. +9 %, the
+                           // cross-stream events cost more than the 0.03-0.04 ms the kernel takes; same file)
 long g_opt_run_phase = 0;  // time-phased stores of the neighbour-exchange run kernel (r04): 0 auto, -1 off, n > 0: phases of 2^n ticks of the 100 MHz counter (12 = 41 us)
 
 // where the neighbour-exchange run kernel is the default: cfg5's shape (r16g16b16a16 at 4x, 15 taps) — measured r04 against the
@@ -987,10 +994,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     *used = false;
     const picha_image &s0 = src[0], &d0 = dst[0];
     const int pixel = d0.pixel, spixel = s0.pixel;   // the format the kernel computes in / the format it loads
-    long opt_run, opt_run_round, opt_numerics, opt_chunks, opt_per_lane, opt_work, opt_work_tail, opt_work_tail_div, opt_bw, opt_run_xch, opt_run_ws, opt_run_phase;
+    long opt_run, opt_run_round, opt_numerics, opt_chunks, opt_per_lane, opt_work, opt_work_tail, opt_work_tail_div, opt_bw, opt_run_xch, opt_run_ws, opt_run_phase, opt_run_edges, opt_run_shu;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
-        opt_run_xch = g_opt_run_xch; opt_run_ws = g_opt_run_ws; opt_run_phase = g_opt_run_phase;
+        opt_run_xch = g_opt_run_xch; opt_run_ws = g_opt_run_ws; opt_run_phase = g_opt_run_phase; opt_run_edges = g_opt_run_edges; opt_run_shu = g_opt_run_shu;
         if (g_opt_xch != 0 && opt_run_xch == 0) opt_run_xch = 2;   // "xch" = 1 / 2 asks for / rules out the exchange forms of the symmetric-table and accumulator kernels: not this one
         opt_run = g_opt_run; opt_run_round = g_opt_run_round; opt_numerics = tl_numerics >= 0 ? tl_numerics : g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
         opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
@@ -1135,7 +1142,13 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     const bool has_edges = rt->c0 > 0 || rt->c1 < d0.width;
     if (xhl >= 0 && rt->x_base != -xhl) RUN_GROUP_NA;
     int stash_words = 0, stash_org[2] = {0, 0};
-    if (has_edges && xhl < 0 && !cv) {
+    // shared unpack (r05, kernels_run.hip RunShu): a lane converts only the pixels its window starts with and takes the rest from lane + 1 through LDS; no stash.
+    // Where instantiated (grey 7.5x) it wins in the reference flavour at 30 / 31 taps only: cfg3b 0.663 -> 0.654 ms (-1.5 % against the stash form, -2.7 % against the
+    // plain form reading the image); fma +1.3 % (that flavour sits at its memory pattern), 21 taps +4 % (13 of 43 window pixels shared: the LDS round trip costs more)
+    const bool shu_ok = !ring_mode && xhl < 0 && !cv && opt_run_shu != 2 && opt_run_edges != 1 &&
+                        run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -2, 1) && (opt_run_shu == 1 || (!fma && ktaps >= 26));
+    const bool use_stash = has_edges && xhl < 0 && !cv && (opt_run_edges == 1 || (opt_run_edges == 0 && pixel == PICHA_GREY && !ring_mode && !shu_ok));
+    if (has_edges && xhl < 0 && !cv) {   // (the stash's applicability rules also hold where the columns now come from the image: the planner's choices are the measured ones)
         const int bpp = kBytes[pixel];
         const int span = ((per_lane - 1) / period) * period_px + (((per_lane - 1) % period) * period_px + ceil_off * (period - 1)) / period + ktaps;  // RunCfg::SPAN
         stash_words = bpp % 4 == 0 ? span * bpp / 4 : (span * bpp + 3) / 4 + 1;                                        // RunCfg::NW
@@ -1200,9 +1213,9 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         if (stash_used) r2 = temp_release(ctx->scratch, s);
         return r1 ? r1 : r2;
     };
-    if (has_edges && opt_run != 3 && (xhl >= 0 || cv)) p.edge_image = 1;
+    if (has_edges && opt_run != 3 && !use_stash) p.edge_image = 1;
     if (cv) { p.cv_on = 1; p.cv_src_pixel = spixel; p.cv_r = cv->r; p.cv_g = cv->g; p.cv_b = cv->b; }
-    if (has_edges && opt_run != 3 && xhl < 0 && !cv) {
+    if (use_stash && opt_run != 3) {
         const size_t bytes = (size_t)n * 2 * s0.height * stash_words * 4;
         if (bytes >= ((size_t)1 << 32)) { (void)release_temps(); RUN_GROUP_NA; }
         if (!temp_lock.owns_lock()) temp_lock.lock();
@@ -1219,7 +1232,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     p.x_groups = x_groups;
     p.x_canon = rt->canon;
     p.fma = fma;
-    p.xch = xhl >= 0 ? 1 : 0; p.wsgpr = wsgpr;
+    const bool shu = shu_ok && wsgpr == 1;
+    p.xch = xhl >= 0 ? 1 : shu ? 2 : 0; p.wsgpr = wsgpr;
     // time-phased stores: where the stores are a thin trickle beside the reads (>= 3 source rows per output row) and the launch is long
     // enough for several phases; 2^12 ticks = 41 us measured best on cfg5 (profiles/r04_ab_run_phase.txt)
     if (xhl >= 0 && opt_run_phase >= 0) p.phase_shift = opt_run_phase > 0 ? (int)std::min(20L, opt_run_phase) : (s0.height >= 3 * d0.height && (long long)n * s0.height >= 20000 ? 12 : 0);
@@ -1263,6 +1277,19 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         (void)release_temps();
         return fail(PICHA_ERR_HIP, "run-kernel resize launch failed: %s", hipGetErrorString(e));
     };
+    auto slice = [&](int done, int m) {   // images [done, done + m) of the group (grid.z limit of the plain grids)
+        RunParams q = p;
+        q.n_images = m;
+        if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
+        else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
+        q.stash_img0 = done;
+        return q;
+    };
+    auto edges_all = [&](hipStream_t es) {
+        hipError_t e = hipSuccess;
+        for (int done = 0; done < n && e == hipSuccess; done += 65535) e = launch_resize_edges_kernel(pixel, slice(done, std::min(n - done, 65535)), es);
+        return e;
+    };
     // launch form: the plain grid (measured r03 on cfg3b: item list +3 %, persistent +30 %; the edge kernel follows either way)
     const int work_mode = !ring_mode && (opt_work == 1 || opt_work == 2) ? (int)opt_work : 0;
     if (work_mode) {
@@ -1281,29 +1308,15 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
             }
         }
         hipError_t e = launch_resize_run_kernel(pixel, p, s, &g_last_kernel);
+        if (e == hipSuccess) e = edges_all(s);
         if (e != hipSuccess) return fail_launch(e);
-        int done = 0;
-        while (done < n) {  // grid.z limit of the edge kernel
-            const int m = std::min(n - done, 65535);
-            RunParams q = p;
-            q.n_images = m;
-            if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
-            else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
-            q.stash_img0 = done;
-            e = launch_resize_edges_kernel(pixel, q, s);
-            if (e != hipSuccess) return fail_launch(e);
-            done += m;
-        }
     } else {
+        hipError_t e = hipSuccess;
         int done = 0;
         while (done < n) {  // grid.z limit
             const int m = std::min(n - done, 65535);
-            RunParams q = p;
-            q.n_images = m;
-            if (p.src_tab) { q.src_tab = p.src_tab + done; q.dst_tab = p.dst_tab + done; }
-            else { q.src = p.src + (long long)done * sp; q.dst = p.dst + (long long)done * dp; }
-            q.stash_img0 = done;
-            hipError_t e = ring_mode ? launch_resize_up_kernel(pixel, q, s, &g_last_kernel) : launch_resize_run_kernel(pixel, q, s, &g_last_kernel);
+            const RunParams q = slice(done, m);
+            e = ring_mode ? launch_resize_up_kernel(pixel, q, s, &g_last_kernel) : launch_resize_run_kernel(pixel, q, s, &g_last_kernel);
             if (e == hipSuccess) e = launch_resize_edges_kernel(pixel, q, s);
             if (e != hipSuccess) return fail_launch(e);
             done += m;
@@ -2430,6 +2443,8 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "run_xch") == 0) { g_opt_run_xch = value; return PICHA_OK; }
     if (strcmp(key, "run_ws") == 0) { g_opt_run_ws = value; return PICHA_OK; }
     if (strcmp(key, "run_phase") == 0) { g_opt_run_phase = value; return PICHA_OK; }
+    if (strcmp(key, "run_shu") == 0) { g_opt_run_shu = value; return PICHA_OK; }
+    if (strcmp(key, "run_edges") == 0) { if (value < 0 || value > 2) return fail(PICHA_ERR_ARGUMENT, "run_edges: 0..2"); g_opt_run_edges = value; return PICHA_OK; }
     if (strcmp(key, "up") == 0) { g_opt_up = value; return PICHA_OK; }
     if (strcmp(key, "work") == 0) { g_opt_work = value; return PICHA_OK; }
     if (strcmp(key, "work_tail") == 0) { g_opt_work_tail = value; return PICHA_OK; }
@@ -2464,6 +2479,8 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "run_xch") == 0) return g_opt_run_xch;
     if (strcmp(key, "run_ws") == 0) return g_opt_run_ws;
     if (strcmp(key, "run_phase") == 0) return g_opt_run_phase;
+    if (strcmp(key, "run_shu") == 0) return g_opt_run_shu;
+    if (strcmp(key, "run_edges") == 0) return g_opt_run_edges;
     if (strcmp(key, "up") == 0) return g_opt_up;
     if (strcmp(key, "work") == 0) return g_opt_work;
     if (strcmp(key, "work_tail") == 0) return g_opt_work_tail;

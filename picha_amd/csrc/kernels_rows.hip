@@ -269,7 +269,10 @@ template <int SCH, bool SS16, int CH, bool S16, int P, int S, int TXB, int KST, 
 hipError_t launch_rows_t(const RowsParams &p, hipStream_t s, const char **name) {
     constexpr int CHL = rows_lds_floats(CH);
     constexpr int PXT = rows_stage_px(SCH * (SS16 ? 2 : 1), CHL);
-    const size_t lds = (size_t)2 * KST * 256 * PXT * CHL * sizeof(float) + 32;  // + slack for the last read of a span that is not a whole number of 8 / 16-byte pieces
+    size_t lds = (size_t)2 * KST * 256 * PXT * CHL * sizeof(float) + 32;  // + slack for the last read of a span that is not a whole number of 8 / 16-byte pieces
+#ifdef PICHA_ROWS_LDS_MIN   // measurement builds: a floor under the workgroup's LDS caps the workgroups per CU (160 KB / floor)
+    if (lds < PICHA_ROWS_LDS_MIN) lds = PICHA_ROWS_LDS_MIN;
+#endif
     auto kf = p.fma ? resize_rows_kernel<SCH, SS16, CH, S16, P, S, TXB, KST, NACC, true> : resize_rows_kernel<SCH, SS16, CH, S16, P, S, TXB, KST, NACC, false>;
     if (lds > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kf), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

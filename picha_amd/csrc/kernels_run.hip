@@ -37,6 +37,8 @@
 namespace picha_hip {
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // first pixel of output o's window relative to the window of output 0 of the same lane
 // (RC = 1: the offsets inside a period round up instead of down — 7.5x with 30 taps: windows at 0, 8, 15, 23 need no padding tap)
 constexpr int run_off(int Q, int PX, int o, int RC = 0) { return (o / Q) * PX + ((o % Q) * PX + RC * (Q - 1)) / Q; }
@@ -275,6 +277,24 @@ template <int CH, bool S16, int Q, int PX, int TX, int P, int XHL> struct RunXch
     static constexpr int NOWN = OWN * DPX, NHL = HL * DPX, NHR = HR * DPX, NH = NHL + NHR;
     static constexpr bool OK = BPP % 4 == 0 && HR >= 0 && HL <= OWN && HR <= OWN && NH <= kWave;
 };
+// XHL == -2 (r05): SHARED UNPACK for 8-bit sub-dword pixels (grey, greya).  In the plain form a lane converts its whole window — at 7.5x / 30 taps 53
+// pixels for four outputs — although the 23 behind its own 30 are the FIRST 23 of lane + 1's window, which that lane converts too (src/resize.cc:110-117
+// redoes the unpack per tap; any arrangement that yields the same float per pixel is the same arithmetic).  Here a lane loads and converts only the
+// OWN = (P / Q) * PX pixels its window starts with, leaves the first NF = (SPAN - OWN) * CH floats of them in wave-private LDS (16-byte chunks,
+// chunk-major: conflict-free b128 writes and reads) and takes the rest of its window from lane + 1's slots.  Lane 63's neighbour is a virtual lane 64:
+// the NF samples behind the wave's run are loaded one BYTE per lane with the row (lane k: sample k), converted by the lanes that loaded them and
+// written to lane 64's slots.  No stash (the lane no longer holds its whole window): the clipped columns come from the image (p.edge_image).
+// Measured upper bound before it was built: -7.7 % on cfg3b (profiles/r04_ablate_run_kernel.txt, PICHA_RUN_ABLATE=5).
+template <int CH, bool S16, int Q, int PX, int TX, int P, int RC> struct RunShu {
+    static constexpr int BPP = CH * Sample<S16>::kBytes;
+    static constexpr int OWN = (P / Q) * PX;
+    static constexpr int SPAN = run_off(Q, PX, P - 1, RC) + TX;
+    static constexpr int HR = SPAN - OWN;            // window pixels held by lane + 1
+    static constexpr int NF = HR * CH;               // floats taken from the neighbour = bytes of the wave's halo
+    static constexpr int NFC = (NF + 3) / 4;         // ... in 16-byte chunks
+    static constexpr int LANES = kWave + 1;          // slots per chunk: 64 lanes + the virtual lane behind the wave
+    static constexpr bool OK = !S16 && BPP < 4 && HR > 0 && HR <= OWN && NF <= kWave;
+};
 // PH (r04): TIME-PHASED STORES.  A finished output row is packed and kept in registers (up to kPhaseRows rows per lane); the wave stores
 // what it holds when the chip-wide 100 MHz counter (s_memrealtime) crosses a multiple of 2^phase_shift ticks — every wave of
 // every workgroup in the same few microseconds — or when it holds kPhaseRows rows, or at the end of its chunk.  Why: in cfg5's march the
@@ -291,12 +311,17 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     using C = RunCfg<CH, S16, Q, PX, TX, P, RC>;
     using X = RunXch<CH, S16, Q, PX, TX, P, XHL>;
     constexpr bool XCH = XHL >= 0;
+    constexpr bool SHU = XHL == -2;
+    using S = RunShu<CH, S16, Q, PX, TX, P, RC>;
+    using CO = EdgeCfg<CH, S16, S::OWN>;   // the lane's own pixels as a byte span (shared-unpack form)
+    static_assert(!SHU || (S::OK && !PH), "shared unpack: 8-bit sub-dword pixels, the neighbour's share within its own pixels");
     static_assert(P % Q == 0, "a lane owns whole periods");
     static_assert(!XCH || (X::OK && RC == 0), "neighbour exchange: dword pixels, halo within one lane's pixels");
     static_assert(WS >= 0 && WS <= Q, "phases with scalar weights");
     static_assert(!PH || C::WORDS, "phased stores: dword-sized pixels");
+    static_assert(!SHU || S::NFC * 4 <= S::OWN * CH, "shared unpack: whole chunks of own floats");
     constexpr int ODW = PH ? P * (C::BPP / 4) : 1;   // dwords of a lane's packed output row
-    constexpr int NRAW = XCH ? X::NOWN + 1 : C::NW;
+    constexpr int NRAW = XCH ? X::NOWN + 1 : SHU ? CO::NW + 1 : C::NW;
     constexpr int NB = XCH ? PICHA_RUN_XNB : (NRAW <= 16 ? PICHA_RUN_NB : 2);  // row buffers
     PICHA_PROBE_BEGIN
     const int lane = threadIdx.x & (kWave - 1);
@@ -341,6 +366,8 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     const int32_t halo_off = halo_k < X::NHL ? grp0 * X::OWN * C::BPP - X::NHL * 4 + 4 * halo_k
                                              : (grp0 + kWave) * X::OWN * C::BPP + 4 * (halo_k - X::NHL);
     __shared__ uint32_t halo_lds[XCH ? 4 * kWave : 1];
+    // shared unpack: lane k fetches sample k of the NF behind the wave's run (the other lanes repeat the last one)
+    [[maybe_unused]] const int32_t shu_halo_off = (p.x_base + (grp0 + kWave) * S::OWN) * C::BPP + sadj + min(lane, S::NF - 1);
 
     const_i32_ptr yrange = (const_i32_ptr)(p.yrow_range);
     const_i32_ptr yrec = (const_i32_ptr)(p.yrow_rec);
@@ -365,6 +392,9 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
 #pragma unroll
             for (int k = 0; k < X::NOWN; ++k) t[k] = __builtin_amdgcn_raw_buffer_load_b32(src_rs, off + 4 * k, 0, 0);
             t[X::NOWN] = __builtin_amdgcn_raw_buffer_load_b32(src_rs, uint32_t(row * p.src_stride + halo_off), 0, 0);
+        } else if constexpr (SHU) {
+            load_span<CO, false>(src_rs, row * p.src_stride + lane_off, t);
+            t[CO::NW] = __builtin_amdgcn_raw_buffer_load_b8(src_rs, uint32_t(row * p.src_stride + shu_halo_off), 0, 0);
         } else {
             load_span<C, false>(src_rs, row * p.src_stride + lane_off, t);
         }
@@ -374,7 +404,12 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     for (int k = 0; k < NB - 1; ++k) {
         const int row = min(r0 + k, r1);
         if constexpr (XCH) { load_row(raw[k], row); }
-        else {
+        else if constexpr (SHU) {
+            if (careful && row <= 0) {
+                load_span<CO, true>(src_rs, row * p.src_stride + lane_off, raw[k]);
+                raw[k][CO::NW] = __builtin_amdgcn_raw_buffer_load_b8(src_rs, uint32_t(row * p.src_stride + shu_halo_off), 0, 0);
+            } else load_row(raw[k], row);
+        } else {
             const int32_t off = row * p.src_stride + lane_off;
             if (careful && row <= 0) load_span<C, true>(src_rs, off, raw[k]);
             else load_span<C, false>(src_rs, off, raw[k]);
@@ -445,7 +480,7 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
         }
     };
     auto process_row = [&](uint32_t (&cur)[NRAW], int row) __attribute__((always_inline)) {
-        if constexpr (!XCH) {
+        if constexpr (!XCH && !SHU) {
             if (st_wave && row <= r1) stash_row(cur, row);  // wave-uniform
         }
         int rec[2 * NACC];
@@ -467,7 +502,32 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
                 for (int c = 0; c < CH; ++c) h[o][c] = __uint_as_float(x & 0x3fffffffu);
         }
 #else
-        uint32_t win[XCH ? C::NW : (C::BROT ? C::NWIN : 1)];
+        uint32_t win[SHU ? CO::NWIN : XCH ? C::NW : (C::BROT ? C::NWIN : 1)];
+        [[maybe_unused]] float uown[SHU ? S::OWN * CH : 1], unext[SHU ? S::NFC * 4 : 1];
+        if constexpr (SHU) {
+            rotate_span<CO>(cur, uint32_t(min(row, r1) * p.src_stride + lane_off) & 3u, win);
+#pragma unroll
+            for (int q = 0; q < S::OWN; ++q) unpack_span_px<CO, CH, S16, FMA>(win, q, &uown[q * CH]);
+            const float uh = FMA ? float(cur[CO::NW]) : unpack_sample<S16>(cur[CO::NW]);
+            f32x4 *xl = reinterpret_cast<f32x4 *>(stash_lds) + wave * (S::NFC * S::LANES);
+#pragma unroll
+            for (int c = 0; c < S::NFC; ++c) {
+                f32x4 v = {uown[4 * c], uown[4 * c + 1], uown[4 * c + 2], uown[4 * c + 3]};   // (NFC * 4 <= OWN * CH + 3: checked below)
+                xl[c * S::LANES + lane] = v;
+            }
+            const int hk = min(lane, S::NF - 1);
+            reinterpret_cast<float *>(xl)[((hk >> 2) * S::LANES + kWave) * 4 + (hk & 3)] = uh;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+            for (int c = 0; c < S::NFC; ++c) {
+                const f32x4 v = xl[c * S::LANES + lane + 1];
+                unext[4 * c] = v[0]; unext[4 * c + 1] = v[1]; unext[4 * c + 2] = v[2]; unext[4 * c + 3] = v[3];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        } else
         if constexpr (C::BROT) rotate_span<C>(cur, uint32_t(min(row, r1) * p.src_stride + lane_off) & 3u, win);
         if constexpr (XCH && PICHA_RUN_ABLATE == 3) {
 #pragma unroll
@@ -504,7 +564,11 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
             if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, qa, u);
             else unpack_span_px<C, CH, S16, FMA>(cur, qa, u);
 #else
-            if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, q, u);
+            if constexpr (SHU) {
+#pragma unroll
+                for (int c = 0; c < CH; ++c) u[c] = q < S::OWN ? uown[q * CH + c] : unext[(q - S::OWN) * CH + c];
+            }
+            else if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, q, u);
             else unpack_span_px<C, CH, S16, FMA>(cur, q, u);
 #endif
 #pragma unroll
@@ -839,7 +903,10 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
     const void *k = p.fma ? reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true, RC, XHL, WS, PH>)
                           : reinterpret_cast<const void *>(resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false, RC, XHL, WS, PH>);
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 4;
-    const size_t lds = p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, Q, PX, TX, P, RC>::NW + 3) / 4 * 4) : 0;   // the stash staging of the edge lanes
+    using SH = RunShu<CH, S16, Q, PX, TX, P, RC>;
+    if (XHL == -2 && p.stash) return hipErrorInvalidValue;   // shared unpack: the clipped columns come from the image
+    const size_t lds = XHL == -2 ? sizeof(float) * 4 * bw * SH::NFC * SH::LANES   // the exchange slots
+                     : p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, Q, PX, TX, P, RC>::NW + 3) / 4 * 4) : 0;   // the stash staging of the edge lanes
     if (p.resident_query) {
         int per_cu = 0, dev = 0, cus = 0;
         hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64 * bw, lds);
@@ -854,6 +921,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
     else resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false, RC, XHL, WS, PH><<<grid, 64 * bw, lds, s>>>(p);
     char form[40] = "";
     if (XHL >= 0) snprintf(form, sizeof form, ",xch%d", XHL);
+    if (XHL == -2) snprintf(form, sizeof form, ",shu");
     if (WS > 0) snprintf(form + strlen(form), sizeof form - strlen(form), ",ws%d", WS);
     if (PH > 0) snprintf(form + strlen(form), sizeof form - strlen(form), ",phased%d", p.phase_shift);
     snprintf(g_kernel_name, sizeof g_kernel_name, "resize_run<ch%d,%s,Q%d,PX%d,TX%d,P%d,NACC%d,%s,bw%d%s%s%s>", CH, S16 ? "u16" : "u8", Q, PX, TX, P, NACC,
@@ -891,7 +959,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // Makefile's -pragma-unroll-threshold; rolled, it indexed its registers dynamically and took 17 ms: -2.5 % exact at 12 chunks, +3 % fma).
 #define PICHA_RUNZ_LIST_0(Z) /* rgb */   /* 7.5x / 21 taps with two or four outputs per lane, scalar phase weights or not: -2 % exact, +7 % fma against resize_acc (r04, as r03 had found): not instantiated */
 #define PICHA_RUNZ_LIST_1(Z) /* rgba */ Z(1, 4, 11, 2, 0, 3, 0) Z(1, 4, 15, 2, 0, 5, 0) Z(1, 3, 8, 2, 0, 2, 0)
-#define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1)
+#define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1) Z(2, 15, 30, 4, 1, -2, 1) Z(2, 15, 31, 4, 0, -2, 1) Z(2, 15, 21, 4, 0, -2, 1)
 #define PICHA_RUNZ_LIST_3(Z) /* greya */ Z(2, 15, 30, 2, 1, -1, 1) Z(2, 15, 31, 2, 0, -1, 1)
 #define PICHA_RUNZ_LIST_4(Z) /* r16 */
 #define PICHA_RUNZ_LIST_5(Z) /* r16g16 */
@@ -963,7 +1031,7 @@ bool PICHA_CAT(run_supported_pixel, PICHA_RUN_PIXEL)(int q, int px, int tx, int 
 hipError_t PICHA_CAT(launch_run_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipStream_t s, const char **name) {
     [[maybe_unused]] constexpr int CH = pixel_channels(PICHA_RUN_PIXEL);
     [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
-    [[maybe_unused]] const int xhl = p.xch ? -p.x_base : -1;
+    [[maybe_unused]] const int xhl = p.xch == 2 ? -2 : p.xch ? -p.x_base : -1;
 #define X(Q, PX, TX, P, RC)                                                                               \
     if (p.period == Q && p.period_px == PX && p.x_taps == TX && p.x_per_lane == P && p.off_ceil == RC && xhl < 0 && p.wsgpr == 0) {  \
         if (p.nacc == 4) return launch_run_t<CH, S16, Q, PX, TX, P, 4, RC>(p, s, name);                   \

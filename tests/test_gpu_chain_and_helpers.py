@@ -620,6 +620,86 @@ def test_run_kernel_scalar_phase_weights_match_oracle(pixel, dw):
             N.check(N.lib().picha_hip_set_option(k, 0))
 
 
+SHU_CASES = [   # source, destination, filter, filter scale: grey at 7.5x in x — the shapes the shared-unpack form is instantiated for
+    ((960, 270), (128, 64), "lanczos", 1.0),        # 30 / 31 taps, one wave per row
+    ((3840, 130), (512, 31), "lanczos", 1.0),       # cfg3b's rows: two waves per row, the second wave's last lane ends the row
+    ((975, 300), (130, 40), "catmulrom", 0.70),     # 21 taps; the last lane's run hangs over the row end (130 = 32 * 4 + 2)
+    ((1950, 77), (260, 20), "cubic", 0.70),         # 21 taps, five waves per row, the last one ragged
+    ((3900, 64), (520, 9), "mitchel", 1.0),         # 31 taps, three waves per row (520 = 2 * 256 + 8)
+    ((30, 40), (4, 7), "lanczos", 1.0),             # one lane: every column is a clipped one
+]
+
+
+@pytest.mark.parametrize("case", SHU_CASES, ids=lambda c: "%dx%d-%s" % (c[0][0], c[0][1], c[2]))
+def test_run_kernel_shared_unpack_matches_oracle(case):
+    """r05: resize_run<..., shu>: a lane converts only the pixels its window starts with and takes the rest of its window, already converted, from
+    lane + 1 through LDS (lane 63 from the samples the wave loads one byte per lane); the clipped columns come from the image.  The same float per
+    window pixel, the same sums in the same order: bit-exact (fma: <= 1).  Against the oracle over both window roundings, row chunkings, launch forms,
+    workgroup widths, padded strides and a sub-view; run_shu = 2 gives the plain form, which must agree byte for byte; run_edges = 1 (the stash)
+    rules the form out."""
+    (sw, sh), (dw, dh), filt, fscale = case
+    rng = np.random.default_rng(sw + 31 * dh)
+    big = rand_image(rng, sw + 8, sh + 3, "grey", pad=int(rng.choice([0, 4, 12])), edge_values=(dw % 3 == 0))
+    keys = (b"run", b"run_shu", b"run_edges", b"run_round", b"row_chunks", b"work", b"block_waves", b"numerics")
+    opts = {"width": dw, "height": dh, "filter": filt, "filterScale": fscale}
+    try:
+        N.check(N.lib().picha_hip_set_option(b"run", 1))
+        for img in (big.subView(0, 0, sw, sh), big.subView(8, 3, sw, sh), big.subView(5, 1, sw, sh)):   # (odd offsets: the row base is not a dword's)
+            want = oracle_resize(img, dw, dh, filt, fscale)
+            for rnd in ((0, 1, 2) if fscale == 1.0 else (0,)):   # (both window roundings where the table has the half-pixel step: 31 / 30 taps)
+                for chunks, work, bw in ((0, 0, 0), (1, 3, 1), (3, 1, 2), (2, 2, 4)):
+                    for k, v in ((b"run_round", rnd), (b"row_chunks", chunks), (b"work", work), (b"block_waves", bw), (b"run_shu", 1), (b"run_edges", 0)):
+                        N.check(N.lib().picha_hip_set_option(k, v))
+                    got = picha.resizeSync(img, opts)
+                    name = N.lib().picha_hip_last_kernel().decode()
+                    if dw >= 8:
+                        assert name.startswith("resize_run<ch1,u8,Q2,PX15,") and ",shu" in name and "+ resize_edges<" in name, name
+                    assert max_code_diff(got, want) == 0, (case, rnd, chunks, work, bw, name)
+                    if name.startswith("resize_run<"):
+                        N.check(N.lib().picha_hip_set_option(b"run_shu", 2))
+                        plain = picha.resizeSync(img, opts)
+                        pname = N.lib().picha_hip_last_kernel().decode()
+                        assert pname.startswith("resize_run<") and ",shu" not in pname, pname
+                        assert max_code_diff(plain, got) == 0, (case, rnd, pname)
+                        N.check(N.lib().picha_hip_set_option(b"run_shu", 1))
+                        N.check(N.lib().picha_hip_set_option(b"run_edges", 1))
+                        picha.resizeSync(img, opts)
+                        assert ",shu" not in N.lib().picha_hip_last_kernel().decode()
+            N.check(N.lib().picha_hip_set_option(b"run_edges", 0))
+            N.check(N.lib().picha_hip_set_option(b"numerics", 1))
+            got = picha.resizeSync(img, opts)
+            assert max_code_diff(got, want) <= 1, (case, N.lib().picha_hip_last_kernel())
+            N.check(N.lib().picha_hip_set_option(b"numerics", 0))
+    finally:
+        for k in keys:
+            N.check(N.lib().picha_hip_set_option(k, 0))
+
+
+@pytest.mark.parametrize("edges", [1, 2])
+@pytest.mark.parametrize("case", [("greya", (960, 130), (128, 31), "lanczos"), ("grey", (960, 130), (128, 31), "lanczos"), ("rgba", (320, 96), (640, 192), None),
+                                  ("grey", (1920, 216), (960, 108), "lanczos"), ("r16", (320, 96), (640, 192), "mitchel")], ids=lambda c: "%s-%s" % (c[0], c[3]))
+def test_edge_columns_from_the_stash_or_the_image_match_oracle(case, edges):
+    """r05: run_edges — resize_edges_kernel takes the clipped columns' windows from the stash the march writes (1) or from the image (2); auto picks per
+    kernel family by measurement.  Both against the oracle on the run, ring and upscale kernels."""
+    pixel, (sw, sh), (dw, dh), filt = case
+    rng = np.random.default_rng(sw + dh + edges)
+    img = rand_image(rng, sw, sh, pixel, pad=4, edge_values=True)
+    opts = {"width": dw, "height": dh}
+    if filt:
+        opts["filter"] = filt
+    want = oracle_resize(img, dw, dh, filt or "cubic", 1.0 if filt else 0.70)
+    try:
+        for k, v in ((b"run", 1), (b"up", 1), (b"run_shu", 2), (b"run_edges", edges)):
+            N.check(N.lib().picha_hip_set_option(k, v))
+        got = picha.resizeSync(img, opts)
+        name = N.lib().picha_hip_last_kernel().decode()
+        assert "+ resize_edges<" in name, name
+        assert max_code_diff(got, want) == 0, (case, edges, name)
+    finally:
+        for k in (b"run", b"up", b"run_shu", b"run_edges"):
+            N.check(N.lib().picha_hip_set_option(k, 0))
+
+
 @pytest.mark.parametrize("case", [
     ("rgba", "grey", 1920, 216, None), ("rgba", "greya", 1920, 216, None), ("rgba", "rgb", 1920, 216, None), ("rgba", "r16", 1536, 120, None),
     ("rgb", "grey", 1920, 216, None), ("r16g16b16a16", "rgba", 1536, 120, None), ("r16g16b16a16", "grey", 1536, 120, None),

@@ -17,7 +17,7 @@ def set_opt(key, v):
 @pytest.fixture(autouse=True)
 def _reset():
     yield
-    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up", "run", "run_round", "run_xch", "run_ws", "run_phase", "fuse"):
+    for k in ("path", "numerics", "per_lane", "row_chunks", "stream_rot", "xcd_remap", "acc", "sym", "block_waves", "cc_mode", "acc_p2", "rows", "xch", "work", "up", "run", "run_round", "run_xch", "run_ws", "run_phase", "run_shu", "run_edges", "fuse"):
         set_opt(k, 0)
 
 
@@ -100,6 +100,8 @@ def test_random_resizes_match_oracle(seed):
         set_opt("xch", int(rng.choice([0, 0, 1, 2])))      # neighbour-exchange forms (r03)
         set_opt("run_xch", int(rng.choice([0, 1, 1, 2])))  # ... of the run kernel (r04), scalar phase weights, time-phased stores
         set_opt("run_ws", int(rng.choice([0, 0, 2])))
+        set_opt("run_shu", int(rng.choice([0, 1, 2])))     # shared unpack (r05); where the clipped columns' windows come from
+        set_opt("run_edges", int(rng.choice([0, 1, 2])))
         set_opt("run_phase", int(rng.choice([0, -1, 5, 9, 12, 20])))
         set_opt("work", int(rng.choice([0, 0, 1, 2, 3])))  # explicit item list / persistent launch / plain grid (r03)
         set_opt("up", int(rng.choice([0, 1, 2])))          # upscales on the accumulator kernel or the span kernel (r03)
@@ -147,6 +149,8 @@ def test_random_half_integer_downscales_match_oracle(seed):
         set_opt("numerics", numerics)
         set_opt("run", int(rng.choice([1, 1, 0])))
         set_opt("run_round", int(rng.choice([0, 0, 1, 2])))
+        set_opt("run_shu", int(rng.choice([0, 1, 1, 2])))
+        set_opt("run_edges", int(rng.choice([0, 0, 1, 2])))
         set_opt("per_lane", int(rng.choice([0, 0, 2, 4, 8])))
         set_opt("row_chunks", int(rng.choice([0, 0, 1, 2, 5])))
         set_opt("work", int(rng.choice([0, 0, 1, 2, 3])))
