@@ -906,23 +906,24 @@ int get_queue(DeviceCtx *ctx, hipStream_t s, unsigned **out, std::shared_ptr<con
 int get_rows_strips(DeviceCtx *ctx, DeviceAxis *ax, const DeviceAxis::XTable *xt, int span_px, int piece_px,
                     const DeviceAxis::RowsStrips **out) {
     std::lock_guard<std::mutex> lk(ctx->mu);
+    constexpr int tw = 256;   // threads per strip (r05: wave-private strips of 64 threads, no barrier, measured a tie on cfg3 and removed: profiles/r05_ab_rows_wave_strips.txt)
     auto key = std::make_tuple((const void *)xt, span_px, piece_px);
     auto it = ax->rows_strips.find(key);
     if (it != ax->rows_strips.end()) { *out = &it->second; return PICHA_OK; }
     DeviceAxis::RowsStrips rs;
     const int groups = xt->groups;
-    const int n_strips = (groups + 255) / 256;
+    const int n_strips = (groups + tw - 1) / tw;
     std::vector<int32_t> sl(n_strips);
     int pieces = 1;
     for (int b = 0; b < n_strips; ++b) {
         int lo = INT32_MAX, hi = INT32_MIN;
-        for (int g = b * 256; g < std::min(groups, b * 256 + 256); ++g) {
+        for (int g = b * tw; g < std::min(groups, b * tw + tw); ++g) {
             lo = std::min(lo, xt->host_left[g]);
             hi = std::max(hi, xt->host_left[g] + span_px);
         }
         lo -= ((lo % piece_px) + piece_px) % piece_px;  // floor to a stage piece
         sl[b] = lo;
-        const int need = (hi - lo + 3 + 256 * piece_px - 1) / (256 * piece_px);  // +3: the last 16-byte read of a span may run past its end
+        const int need = (hi - lo + 3 + tw * piece_px - 1) / (tw * piece_px);  // +3: the last 16-byte read of a span may run past its end
         while (pieces < need) pieces *= 2;
     }
     pieces = std::max(pieces, 2);  // instantiated: 2, 4, 8
@@ -1052,6 +1053,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
                     else {
                         for (int na : {4, 6})
                             any = any || run_kernel_supported(pixel, period, period_px, tx, pl, na, c) || run_kernel_supported(pixel, period, period_px, tx, pl, na, c, -1, 1) ||
+                                  run_kernel_supported(pixel, period, period_px, tx, pl, na, c, -2, std::min(2, period)) ||
                                   (c == 0 && xb0 <= 0 && run_kernel_supported(pixel, period, period_px, tx, pl, na, 0, -xb0, 0));
                         for (int k : {8, 16}) any = any || up_kernel_supported(pixel, period, period_px, tx, pl, c, k, ay->host.taps);
                     }
@@ -1115,7 +1117,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         for (int tx = tx_of[c]; tx <= tx_of[c] + 3 && !per_lane; ++tx)
             for (int pl0 : (up || (period == 2 && period_px == 3) ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
                 const int pl = opt_per_lane > 0 ? (int)opt_per_lane : pl0;   // "per_lane" names the run length outright
-                if (pl <= 0 || pl % period || !(cv ? up_cv_kernel_supported(pixel, spixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : (run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c) || (opt_run_ws != 2 && run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c, -1, 1))))) continue;
+                if (pl <= 0 || pl % period || !(cv ? up_cv_kernel_supported(pixel, spixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : (run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c) || (opt_run_ws != 2 && (run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c, -1, 1) || run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c, -2, std::min(2, period))))))) continue;
                 per_lane = pl; ktaps = tx; ceil_off = c;
                 break;
             }
@@ -1127,7 +1129,12 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // ... and the other instantiated shapes of one- and two-channel pixels (1.5x: grey -31 %, greya -9 %; 2.5x / 3x / 4x / 5x: -11 .. -26 %,
     // measured on 128-256 images); the 21-tap 7.5x shape was a tie for greya and needs >= 192 images for grey
     const int ch = kChannels[pixel];
-    const bool short_ok = period_px == 15 ? (ch == 1 && n >= 192) : (ch <= 2 && n >= 96);
+    // (r05) rgb exists in the shared-unpack form only (7.5x / 6x / 8x with picha's defaults: the jpeg thumbnail -10 % / fma -9 %, 4K -> 640x360 -13 % / -9 %,
+    // -> 480x270 -13 % / -10 %, 8K -> 1024x576 -11 % against the accumulator kernel; 32 4K images -14 %, 16 of them or 64 x 1080p -> 256x144 +7 %: launches of
+    // >= 200 000 wave-rows; profiles/r05_ab_shu_rgb.txt, r05_ab_shu_rgb_defaults.txt)
+    const bool shu_only = !ring_mode && xhl < 0 && !run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off) && !run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -1, 1);
+    const long long wave_cols = (long long)n * (((d0.width + per_lane - 1) / per_lane + 63) / 64);
+    const bool short_ok = shu_only ? wave_cols * s0.height >= 200000 : period_px == 15 ? (ch == 1 && n >= 192) : (ch <= 2 && n >= 96);
     if (!ring_mode && xhl < 0 && opt_run == 0 && ktaps < 26 && !short_ok) RUN_GROUP_NA;
     // one phase's weights in SGPRs (r04): where instantiated — the 7.5x shapes, whose 2 x 30 lane-uniform weight registers held the
     // kernel at 3 waves per SIMD (profiles/r04_ab_run_ws.txt)
@@ -1142,11 +1149,12 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     const bool has_edges = rt->c0 > 0 || rt->c1 < d0.width;
     if (xhl >= 0 && rt->x_base != -xhl) RUN_GROUP_NA;
     int stash_words = 0, stash_org[2] = {0, 0};
-    // shared unpack (r05, kernels_run.hip RunShu): a lane converts only the pixels its window starts with and takes the rest from lane + 1 through LDS; no stash.
-    // Where instantiated (grey 7.5x) it wins in the reference flavour at 30 / 31 taps only: cfg3b 0.663 -> 0.654 ms (-1.5 % against the stash form, -2.7 % against the
-    // plain form reading the image); fma +1.3 % (that flavour sits at its memory pattern), 21 taps +4 % (13 of 43 window pixels shared: the LDS round trip costs more)
-    const bool shu_ok = !ring_mode && xhl < 0 && !cv && opt_run_shu != 2 && opt_run_edges != 1 &&
-                        run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -2, 1) && (opt_run_shu == 1 || (!fma && ktaps >= 26));
+    // shared unpack (r05, kernels_run.hip RunShu): a lane converts only the pixels its window starts with and takes the rest from lane + 1 through LDS; no stash;
+    // both phases' weights in SGPRs, two row buffers, five waves per SIMD.  The default in the reference flavour wherever instantiated (grey 7.5x): cfg3b 0.678 -> 0.652 ms
+    // (-3.8 % against the r03 form), 21 taps -2.9 %; the fma flavour sits at its memory pattern (+-0.5 %) and keeps the r03 form (profiles/r05_ab_shu_final.txt)
+    const bool shu_ok = !ring_mode && xhl < 0 && !cv && opt_run_shu != 2 && opt_run_ws != 2 && opt_run_edges != 1 &&
+                        run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -2, std::min(2, period)) && (opt_run_shu == 1 || !fma || shu_only);
+    if (shu_only && !shu_ok) RUN_GROUP_NA;
     const bool use_stash = has_edges && xhl < 0 && !cv && (opt_run_edges == 1 || (opt_run_edges == 0 && pixel == PICHA_GREY && !ring_mode && !shu_ok));
     if (has_edges && xhl < 0 && !cv) {   // (the stash's applicability rules also hold where the columns now come from the image: the planner's choices are the measured ones)
         const int bpp = kBytes[pixel];
@@ -1232,8 +1240,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     p.x_groups = x_groups;
     p.x_canon = rt->canon;
     p.fma = fma;
-    const bool shu = shu_ok && wsgpr == 1;
-    p.xch = xhl >= 0 ? 1 : shu ? 2 : 0; p.wsgpr = wsgpr;
+    const bool shu = shu_ok;
+    p.xch = xhl >= 0 ? 1 : shu ? 2 : 0; p.wsgpr = shu ? std::min(2, period) : wsgpr;   // (the shared-unpack shapes keep both phases' weights in SGPRs)
     // time-phased stores: where the stores are a thin trickle beside the reads (>= 3 source rows per output row) and the launch is long
     // enough for several phases; 2^12 ticks = 41 us measured best on cfg5 (profiles/r04_ab_run_phase.txt)
     if (xhl >= 0 && opt_run_phase >= 0) p.phase_shift = opt_run_phase > 0 ? (int)std::min(20L, opt_run_phase) : (s0.height >= 3 * d0.height && (long long)n * s0.height >= 20000 ? 12 : 0);
@@ -1246,6 +1254,9 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     p.y_count = ay->count; p.y_eff = ay->eff; p.y_weight = ay->weight; p.y_taps = ay->host.taps;
     const int col_waves = (p.x_groups + 63) / 64;
     p.block_waves = opt_bw >= 1 && opt_bw <= 4 ? (int)opt_bw : std::min(4, col_waves);
+    // (r05, the rgb shared-unpack shapes: 10 KB of exchange slots per wave, so an idle wave of a ragged workgroup costs a resident one: five wave columns run as
+    //  2 + 2 + 1 rather than 4 + 1 — 4K -> 640x360: -13 % against +1 %)
+    if (!(opt_bw >= 1 && opt_bw <= 4) && shu_only && col_waves > 4 && col_waves % 2 < (4 - col_waves % 4) % 4) p.block_waves = 2;
     const int nsb = (col_waves + p.block_waves - 1) / p.block_waves;
     // row chunks: as for the accumulator kernel (>= ~8 K waves, the re-resampled halo of a chunk under ~6 % of its rows)
     const int ring = std::max(ay->host.span, 1);
@@ -1267,6 +1278,13 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         const int resident = run_kernel_resident_blocks(pixel, p);
         const long long two_rounds = resident > 0 ? (2LL * resident + (long long)nsb * n - 1) / ((long long)nsb * n) : chunks;
         chunks = std::max<long long>(1, std::min(chunks, std::max(by_halo3, two_rounds)));
+    }
+    if (opt_chunks <= 0 && shu) {
+        // the shared-unpack form: one whole round of resident workgroups where the halo rule allows it (cfg3b: 5 waves per SIMD = 2560 two-wave workgroups = 10
+        // chunks of 256 images: -2 % against 8, +1.5 % at 12; profiles/r05_ab_shu_occupancy.txt)
+        const int resident = run_kernel_resident_blocks(pixel, p);
+        const long long round = resident > 0 ? resident / ((long long)nsb * n) : 0;
+        if (shu_only ? (round >= 2 && round <= chunks) : (round >= chunks && round <= 2 * chunks)) chunks = round;   // (rgb, LDS-bound residency: the jpeg thumbnail 11 -> 4 chunks -5 %)
     }
     // small launches (a single image): chunks of down to one row for about 3000 waves, as for the accumulator kernel
     if (opt_chunks <= 0 && (long long)n * col_waves * chunks < 3000)

@@ -33,6 +33,18 @@
 #ifndef PICHA_RUN_ABLATE
 #define PICHA_RUN_ABLATE 0
 #endif
+// measurement builds: -DPICHA_RUN_WAVES=N makes the compiler fit resize_run_kernel into the registers of N waves per SIMD
+// ... and -DPICHA_RUN_WS_AS=2 launches the shapes listed with one scalar phase with BOTH phases' weights in SGPRs
+#ifdef PICHA_RUN_WS_AS
+#define PICHA_RUN_WS_OF(WS) ((WS) == 1 ? PICHA_RUN_WS_AS : (WS))
+#else
+#define PICHA_RUN_WS_OF(WS) (WS)
+#endif
+#ifdef PICHA_RUN_WAVES
+#define PICHA_RUN_WAVES_ATTR __attribute__((amdgpu_waves_per_eu(PICHA_RUN_WAVES, PICHA_RUN_WAVES)))
+#else
+#define PICHA_RUN_WAVES_ATTR
+#endif
 
 namespace picha_hip {
 namespace {
@@ -307,7 +319,7 @@ template <int CH, bool S16, int Q, int PX, int TX, int P, int RC> struct RunShu 
 #endif
 constexpr int kPhaseRows = PICHA_RUN_PHASE_ROWS;
 template <int CH, bool S16, int Q, int PX, int TX, int P, int NACC, bool FMA, int RC = 0, int XHL = -1, int WS = 0, int PH = 0>
-__global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
+__global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(RunParams p) {
     using C = RunCfg<CH, S16, Q, PX, TX, P, RC>;
     using X = RunXch<CH, S16, Q, PX, TX, P, XHL>;
     constexpr bool XCH = XHL >= 0;
@@ -322,7 +334,7 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     static_assert(!SHU || S::NFC * 4 <= S::OWN * CH, "shared unpack: whole chunks of own floats");
     constexpr int ODW = PH ? P * (C::BPP / 4) : 1;   // dwords of a lane's packed output row
     constexpr int NRAW = XCH ? X::NOWN + 1 : SHU ? CO::NW + 1 : C::NW;
-    constexpr int NB = XCH ? PICHA_RUN_XNB : (NRAW <= 16 ? PICHA_RUN_NB : 2);  // row buffers
+    constexpr int NB = XCH ? PICHA_RUN_XNB : SHU ? 2 : (NRAW <= 16 ? PICHA_RUN_NB : 2);  // row buffers
     PICHA_PROBE_BEGIN
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -672,6 +684,17 @@ __global__ __launch_bounds__(256) void resize_run_kernel(RunParams p) {
     PICHA_PROBE_END
 }
 
+// register budget of resize_ring_kernel in waves per SIMD (r05): lanczos 2x on rgba compiles to 131 VGPRs — three waves per SIMD, and an odd number of co-resident waves
+// issues at 2.74 cycles per instruction instead of 2.05 (profiles/r05_ubench_valu_issue.txt); held to 128 (five spilled dwords) it runs 3.3 % faster, fma 2.1 %
+// (profiles/r05_ab_reg_budgets.txt).  Every other shape keeps what the compiler picks (the 4x upscales would spill 80-100 dwords under 128).
+constexpr int ring_min_waves(int ch, bool s16, int q, int px, int tx, int p, int k, int srcp) {
+#ifdef PICHA_RING_WAVES
+    return PICHA_RING_WAVES;   // measurement builds
+#else
+    return (ch == 4 && !s16 && q == 1 && px == 2 && tx == 9 && p == 2 && k == 8 && srcp < 0) ? 4 : 1;
+#endif
+}
+
 // compile-time helpers of resize_ring_kernel: call f(integral_constant<i>) for the run-time i in [0, N) / for every i in [0, N)
 template <int N, int I = 0, typename Fn> __device__ __forceinline__ void switch_slot(int i, Fn &&f) {
     if constexpr (I + 1 == N) { f(std::integral_constant<int, I>{}); }
@@ -699,7 +722,7 @@ template <int N, int I = 0, typename Fn> __device__ __forceinline__ void unroll_
 //     format SRCP and every window pixel is converted and quantised in registers (convert_span_px) before it meets its weights; the clipped
 //     columns are recomputed from the image by resize_edges_kernel<..., SRCP> (no stash).
 template <int CH, bool S16, int Q, int PX, int TX, int P, int K, int TYM, bool FMA, int RC, int SRCP = -1>
-__global__ __launch_bounds__(256) void resize_ring_kernel(RunParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ring_min_waves(CH, S16, Q, PX, TX, P, K, SRCP)))) void resize_ring_kernel(RunParams p) {
     using C = RunCfg<CH, S16, Q, PX, TX, P, RC>;
     constexpr int SCH = SRCP < 0 ? CH : pixel_channels(SRCP < 0 ? 0 : SRCP);
     constexpr bool SS16 = SRCP < 0 ? S16 : pixel_is16(SRCP < 0 ? 0 : SRCP);
@@ -954,12 +977,14 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // r04 forms: Z(Q, PX, TX, P, RC, XHL, WS) — XHL >= 0: neighbour exchange with XHL window pixels in front of the lane's own (dword-sized
 // pixels, integer scales: cfg5 = 8K r16g16b16a16 at 4x, 15 taps, windows start 5 pixels before the lane's own eight); WS: phases of the
 // period whose weights stay in SGPRs (cfg3b: one of the two phases of 7.5x).
+// (r05) the shared-unpack shapes (XHL = -2) keep BOTH phases' weights in SGPRs and two row buffers: 87 VGPRs, five waves per SIMD (-4.5 % against one scalar phase
+// and three buffers at 114; a 6- or 8-wave register budget spills and loses: profiles/r05_ab_shu_occupancy.txt).
 // Measured and not kept (profiles/r04_ab_run_ws.txt): both phases scalar (97 VGPRs, one short of a fifth wave per SIMD: +2 % exact, +12 % fma),
 // two row buffers instead of three (a tie), eight outputs per lane for the 30-tap shape (143 VGPRs once its 82-pixel window loop unrolls — see the
 // Makefile's -pragma-unroll-threshold; rolled, it indexed its registers dynamically and took 17 ms: -2.5 % exact at 12 chunks, +3 % fma).
-#define PICHA_RUNZ_LIST_0(Z) /* rgb */   /* 7.5x / 21 taps with two or four outputs per lane, scalar phase weights or not: -2 % exact, +7 % fma against resize_acc (r04, as r03 had found): not instantiated */
+#define PICHA_RUNZ_LIST_0(Z) /* rgb */ Z(2, 15, 21, 2, 0, -2, 2) Z(1, 6, 17, 2, 0, -2, 1) Z(1, 8, 23, 2, 0, -2, 1)  /* (r05) shared unpack only; the plain forms at 7.5x / 21 taps (two or four outputs per lane, scalar phase weights or not) were -2 % exact, +7 % fma against resize_acc (r04, as r03 had found): not instantiated */
 #define PICHA_RUNZ_LIST_1(Z) /* rgba */ Z(1, 4, 11, 2, 0, 3, 0) Z(1, 4, 15, 2, 0, 5, 0) Z(1, 3, 8, 2, 0, 2, 0)
-#define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1) Z(2, 15, 30, 4, 1, -2, 1) Z(2, 15, 31, 4, 0, -2, 1) Z(2, 15, 21, 4, 0, -2, 1)
+#define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1) Z(2, 15, 30, 4, 1, -2, 2) Z(2, 15, 31, 4, 0, -2, 2) Z(2, 15, 21, 4, 0, -2, 2)
 #define PICHA_RUNZ_LIST_3(Z) /* greya */ Z(2, 15, 30, 2, 1, -1, 1) Z(2, 15, 31, 2, 0, -1, 1)
 #define PICHA_RUNZ_LIST_4(Z) /* r16 */
 #define PICHA_RUNZ_LIST_5(Z) /* r16g16 */
@@ -1045,8 +1070,8 @@ hipError_t PICHA_CAT(launch_run_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hipS
             if (p.phase_shift > 0 && p.nacc == 4) return launch_run_t<CH, S16, Q, PX, TX, P, 4, RC, XHL, WS, 1>(p, s, name); \
             if (p.phase_shift > 0 && p.nacc == 6) return launch_run_t<CH, S16, Q, PX, TX, P, 6, RC, XHL, WS, 1>(p, s, name); \
         }                                                                                                  \
-        if (p.nacc == 4) return launch_run_t<CH, S16, Q, PX, TX, P, 4, RC, XHL, WS>(p, s, name);          \
-        if (p.nacc == 6) return launch_run_t<CH, S16, Q, PX, TX, P, 6, RC, XHL, WS>(p, s, name);          \
+        if (p.nacc == 4) return launch_run_t<CH, S16, Q, PX, TX, P, 4, RC, XHL, PICHA_RUN_WS_OF(WS)>(p, s, name);          \
+        if (p.nacc == 6) return launch_run_t<CH, S16, Q, PX, TX, P, 6, RC, XHL, PICHA_RUN_WS_OF(WS)>(p, s, name);          \
     }
     PICHA_RUNZ_LIST(Z)
 #undef Z

@@ -608,38 +608,42 @@ def test_run_kernel_scalar_phase_weights_match_oracle(pixel, dw):
                 N.check(N.lib().picha_hip_set_option(b"run_ws", ws))
                 got = picha.resizeSync(img, opts)
                 name = N.lib().picha_hip_last_kernel().decode()
-                assert name.startswith("resize_run<") and (",ws1" in name) == (ws == 0), name
+                assert name.startswith("resize_run<") and (",ws" in name) == (ws == 0), name   # (",ws2" in the shared-unpack form)
                 assert max_code_diff(got, want) == 0, (pixel, rnd, ws, name)
         for k in (b"run_round", b"run_ws"):
             N.check(N.lib().picha_hip_set_option(k, 0))
         N.check(N.lib().picha_hip_set_option(b"numerics", 1))
         got = picha.resizeSync(img, opts)
-        assert ",ws1" in N.lib().picha_hip_last_kernel().decode() and max_code_diff(got, want) <= 1
+        assert ",ws" in N.lib().picha_hip_last_kernel().decode() and max_code_diff(got, want) <= 1
     finally:
         for k in (b"run_round", b"run_ws", b"numerics"):
             N.check(N.lib().picha_hip_set_option(k, 0))
 
 
-SHU_CASES = [   # source, destination, filter, filter scale: grey at 7.5x in x — the shapes the shared-unpack form is instantiated for
-    ((960, 270), (128, 64), "lanczos", 1.0),        # 30 / 31 taps, one wave per row
-    ((3840, 130), (512, 31), "lanczos", 1.0),       # cfg3b's rows: two waves per row, the second wave's last lane ends the row
-    ((975, 300), (130, 40), "catmulrom", 0.70),     # 21 taps; the last lane's run hangs over the row end (130 = 32 * 4 + 2)
-    ((1950, 77), (260, 20), "cubic", 0.70),         # 21 taps, five waves per row, the last one ragged
-    ((3900, 64), (520, 9), "mitchel", 1.0),         # 31 taps, three waves per row (520 = 2 * 256 + 8)
-    ((30, 40), (4, 7), "lanczos", 1.0),             # one lane: every column is a clipped one
+SHU_CASES = [   # pixel, source, destination, filter, filter scale: the shapes the shared-unpack form is instantiated for (grey at 7.5x; rgb at 7.5x / 6x / 8x, 21 / 17 / 23 taps)
+    ("grey", (960, 270), (128, 64), "lanczos", 1.0),        # 30 / 31 taps, one wave per row
+    ("grey", (3840, 130), (512, 31), "lanczos", 1.0),       # cfg3b's rows: two waves per row, the second wave's last lane ends the row
+    ("grey", (975, 300), (130, 40), "catmulrom", 0.70),     # 21 taps; the last lane's run hangs over the row end (130 = 32 * 4 + 2)
+    ("grey", (1950, 77), (260, 20), "cubic", 0.70),         # 21 taps, five waves per row, the last one ragged
+    ("grey", (3900, 64), (520, 9), "mitchel", 1.0),         # 31 taps, three waves per row (520 = 2 * 256 + 8)
+    ("grey", (30, 40), (4, 7), "lanczos", 1.0),             # one lane: every column is a clipped one
+    ("rgb", (3840, 150), (512, 20), "cubic", 0.70),         # the jpeg thumbnail's rows: 7.5x, 21 taps, two outputs per lane, four waves per row
+    ("rgb", (975, 121), (130, 16), "catmulrom", 0.70),      # ... ragged: 65 lanes
+    ("rgb", (1920, 100), (320, 17), "mitchel", 0.70),       # 6x, 17 taps (period 1: every weight scalar)
+    ("rgb", (2056, 90), (257, 11), "cubic", 0.70),          # 8x, 23 taps, an odd output width
 ]
 
 
-@pytest.mark.parametrize("case", SHU_CASES, ids=lambda c: "%dx%d-%s" % (c[0][0], c[0][1], c[2]))
+@pytest.mark.parametrize("case", SHU_CASES, ids=lambda c: "%s-%dx%d-%s" % (c[0], c[1][0], c[1][1], c[3]))
 def test_run_kernel_shared_unpack_matches_oracle(case):
     """r05: resize_run<..., shu>: a lane converts only the pixels its window starts with and takes the rest of its window, already converted, from
     lane + 1 through LDS (lane 63 from the samples the wave loads one byte per lane); the clipped columns come from the image.  The same float per
     window pixel, the same sums in the same order: bit-exact (fma: <= 1).  Against the oracle over both window roundings, row chunkings, launch forms,
     workgroup widths, padded strides and a sub-view; run_shu = 2 gives the plain form, which must agree byte for byte; run_edges = 1 (the stash)
     rules the form out."""
-    (sw, sh), (dw, dh), filt, fscale = case
+    pixel, (sw, sh), (dw, dh), filt, fscale = case
     rng = np.random.default_rng(sw + 31 * dh)
-    big = rand_image(rng, sw + 8, sh + 3, "grey", pad=int(rng.choice([0, 4, 12])), edge_values=(dw % 3 == 0))
+    big = rand_image(rng, sw + 8, sh + 3, pixel, pad=int(rng.choice([0, 4, 12])), edge_values=(dw % 3 == 0))
     keys = (b"run", b"run_shu", b"run_edges", b"run_round", b"row_chunks", b"work", b"block_waves", b"numerics")
     opts = {"width": dw, "height": dh, "filter": filt, "filterScale": fscale}
     try:
@@ -653,13 +657,13 @@ def test_run_kernel_shared_unpack_matches_oracle(case):
                     got = picha.resizeSync(img, opts)
                     name = N.lib().picha_hip_last_kernel().decode()
                     if dw >= 8:
-                        assert name.startswith("resize_run<ch1,u8,Q2,PX15,") and ",shu" in name and "+ resize_edges<" in name, name
+                        assert name.startswith("resize_run<ch%d,u8,Q" % (1 if pixel == "grey" else 3)) and ",shu" in name and "+ resize_edges<" in name, name
                     assert max_code_diff(got, want) == 0, (case, rnd, chunks, work, bw, name)
                     if name.startswith("resize_run<"):
                         N.check(N.lib().picha_hip_set_option(b"run_shu", 2))
                         plain = picha.resizeSync(img, opts)
                         pname = N.lib().picha_hip_last_kernel().decode()
-                        assert pname.startswith("resize_run<") and ",shu" not in pname, pname
+                        assert ",shu" not in pname and pname.startswith("resize_run<" if pixel == "grey" else "resize_"), pname   # (rgb: no plain run kernel)
                         assert max_code_diff(plain, got) == 0, (case, rnd, pname)
                         N.check(N.lib().picha_hip_set_option(b"run_shu", 1))
                         N.check(N.lib().picha_hip_set_option(b"run_edges", 1))
