@@ -967,7 +967,7 @@ long g_opt_run_xch = 0;    // its neighbour-exchange form (dword-sized pixels, i
 long g_opt_run_ws = 0;     // weights of one phase of the period in SGPRs (r04): 0 auto, 1 wherever instantiated, 2 never
 long g_opt_run_shu = 0;    // shared unpack through LDS (r05; 8-bit grey / greya, kernels_run.hip RunShu): 0 auto (wherever instantiated), 1 the same, 2 never
 long g_opt_run_edges = 0;  // where resize_edges_kernel takes the clipped columns' windows from (it follows the march on the same stream either way): 0 auto, 1 a stash the march
-                           // writes (r03 form; the image where the form has no stash), 2 the image.  Auto = the measured winner (profiles/r05_ab_run_edges_shu.txt): the
+                           // writes (r03 form; the image where the form has no stash), 2 the image, 3 = 0.  Auto = the measured winner (profiles/r05_ab_run_edges_shu.txt): the
                            // stash for the plain grey run kernel only (-1.3 .. -1.9 % against the image); greya, the ring / upscale kernels and the shared-unpack form read
                            // the image (greya 7.5x -5 %, rgba 2x upscale -4 %, grey lanczos 2x -2.6 %: their stash rows are longer than the lines the image costs).
                            // (r05, measured and removed: the edge kernel on a second stream BESIDE a march that leaves those columns alone — +5 .. +9 %, the
@@ -1155,8 +1155,20 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     const bool shu_ok = !ring_mode && xhl < 0 && !cv && opt_run_shu != 2 && opt_run_ws != 2 && opt_run_edges != 1 &&
                         run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -2, std::min(2, period)) && (opt_run_shu == 1 || !fma || shu_only);
     if (shu_only && !shu_ok) RUN_GROUP_NA;
-    const bool use_stash = has_edges && xhl < 0 && !cv && (opt_run_edges == 1 || (opt_run_edges == 0 && pixel == PICHA_GREY && !ring_mode && !shu_ok));
-    if (has_edges && xhl < 0 && !cv) {   // (the stash's applicability rules also hold where the columns now come from the image: the planner's choices are the measured ones)
+    // (r05) the upscale shapes of the ring kernel produce the clipped columns themselves from those columns' own weights, zero-padded into the canonical window
+    // (kernels_run.hip EIN): no stash, no edge kernel — where every clipped column's taps lie inside its canonical window
+    bool edges_inside = ring_mode && has_edges && (opt_run_edges == 0 || opt_run_edges == 3) && opt_run != 3 && up_edges_inside(period, period_px, ktaps, per_lane);
+    if (edges_inside) {
+        const AxisTaps &tx = ax->host;
+        auto offg = [&](int x) { return (x / period) * period_px + ((x % period) * period_px + ceil_off * (period - 1)) / period; };
+        for (int x = 0; x < d0.width && edges_inside; ++x) {
+            if (x >= rt->c0 && x < rt->c1) continue;
+            const int first = tx.left[x] - (rt->x_base + offg(x));
+            if (first < 0 || first + tx.count[x] > ktaps) edges_inside = false;
+        }
+    }
+    const bool use_stash = !edges_inside && has_edges && xhl < 0 && !cv && (opt_run_edges == 1 || (opt_run_edges == 0 && pixel == PICHA_GREY && !ring_mode && !shu_ok));
+    if (has_edges && xhl < 0 && !cv && !edges_inside) {   // (the stash's applicability rules also hold where the columns now come from the image: the planner's choices are the measured ones)
         const int bpp = kBytes[pixel];
         const int span = ((per_lane - 1) / period) * period_px + (((per_lane - 1) % period) * period_px + ceil_off * (period - 1)) / period + ktaps;  // RunCfg::SPAN
         stash_words = bpp % 4 == 0 ? span * bpp / 4 : (span * bpp + 3) / 4 + 1;                                        // RunCfg::NW
@@ -1221,7 +1233,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         if (stash_used) r2 = temp_release(ctx->scratch, s);
         return r1 ? r1 : r2;
     };
-    if (has_edges && opt_run != 3 && !use_stash) p.edge_image = 1;
+    if (has_edges && opt_run != 3 && !use_stash && !edges_inside) p.edge_image = 1;
+    if (edges_inside) p.edge_in = 1;
     if (cv) { p.cv_on = 1; p.cv_src_pixel = spixel; p.cv_r = cv->r; p.cv_g = cv->g; p.cv_b = cv->b; }
     if (use_stash && opt_run != 3) {
         const size_t bytes = (size_t)n * 2 * s0.height * stash_words * 4;
@@ -2462,7 +2475,7 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "run_ws") == 0) { g_opt_run_ws = value; return PICHA_OK; }
     if (strcmp(key, "run_phase") == 0) { g_opt_run_phase = value; return PICHA_OK; }
     if (strcmp(key, "run_shu") == 0) { g_opt_run_shu = value; return PICHA_OK; }
-    if (strcmp(key, "run_edges") == 0) { if (value < 0 || value > 2) return fail(PICHA_ERR_ARGUMENT, "run_edges: 0..2"); g_opt_run_edges = value; return PICHA_OK; }
+    if (strcmp(key, "run_edges") == 0) { if (value < 0 || value > 3) return fail(PICHA_ERR_ARGUMENT, "run_edges: 0..3"); g_opt_run_edges = value; return PICHA_OK; }
     if (strcmp(key, "up") == 0) { g_opt_up = value; return PICHA_OK; }
     if (strcmp(key, "work") == 0) { g_opt_work = value; return PICHA_OK; }
     if (strcmp(key, "work_tail") == 0) { g_opt_work_tail = value; return PICHA_OK; }

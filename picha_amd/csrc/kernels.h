@@ -284,6 +284,7 @@ struct RunParams {
     int xch;         // 1: neighbour exchange — a lane loads only its own (x_per_lane / period) * period_px pixels (dword-sized pixels; x_base <= 0 is minus the window pixels in front of them)
     int wsgpr;       // phases of the period whose weights stay in SGPRs (0 .. period)
     int edge_image;  // 1: resize_edges_kernel reads the edge columns' windows from the image, not from a stash
+    int edge_in;     // 1 (r05, resize_ring_kernel shapes with up_edges_inside()): the march takes the clipped columns' own weights and produces them itself — no edge kernel
     int phase_shift; // > 0 (neighbour-exchange shapes): time-phased stores — finished rows wait in registers until s_memrealtime >> phase_shift changes
     // colour convert in front of an integer upscale (r04, resize_ring_kernel / resize_edges_kernel): the source images are in cv_src_pixel, every window
     // pixel goes through src/colorconvert.cc:136-152 (unpack, channel map, pack = the intermediate image's quantised samples) in registers and is then
@@ -296,6 +297,7 @@ hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s
 // ring-in-registers kernel (integer upscales: period = the factor, period_px = 1, ring 4; ring-aliased downscales: ring = the
 // reference's): yrow_rec unused; yrow_range: per output row {first source row needed by it or any later row, last row so far}
 bool up_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int off_ceil, int ring_rows, int y_taps);
+constexpr bool up_edges_inside(int period, int period_px, int taps, int per_lane) { return period > period_px && per_lane * taps <= 24; }   // == ring_edges_inside (kernels_run.hip)
 hipError_t launch_resize_up_kernel(int pixel, const RunParams &p, hipStream_t s, const char **kernel_name);
 bool up_cv_kernel_supported(int pixel, int src_pixel, int period, int period_px, int taps, int per_lane, int off_ceil, int ring_rows, int y_taps);  // p.cv_on forms
 hipError_t launch_resize_edges_kernel(int pixel, const RunParams &p, hipStream_t s);  // after the run kernel, same stream: the columns outside [cx0, cx1)

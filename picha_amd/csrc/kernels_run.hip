@@ -695,6 +695,10 @@ constexpr int ring_min_waves(int ch, bool s16, int q, int px, int tx, int p, int
 #endif
 }
 
+// shapes of resize_ring_kernel that can produce the clipped edge columns themselves (EIN): upscales (more outputs than source pixels per period) whose
+// per-output weight sets are at most 24 registers
+__host__ __device__ constexpr bool ring_edges_inside(int q, int px, int tx, int p) { return q > px && p * tx <= 24; }
+
 // compile-time helpers of resize_ring_kernel: call f(integral_constant<i>) for the run-time i in [0, N) / for every i in [0, N)
 template <int N, int I = 0, typename Fn> __device__ __forceinline__ void switch_slot(int i, Fn &&f) {
     if constexpr (I + 1 == N) { f(std::integral_constant<int, I>{}); }
@@ -752,11 +756,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ring_min_wa
     int32_t wbits[F * TX];
 #pragma unroll
     for (int j = 0; j < F * TX; ++j) wbits[j] = xc[j];
-    float wx[F][TX];
+    // EIN (r05): EDGE COLUMNS INSIDE — short runs of short windows (integer upscales) keep one weight set per OUTPUT of the lane instead of one per phase; with
+    // p.edge_in the lanes that hold clipped columns load those columns' own weights (src/resize.cc:19-50: fewer taps, renormalised), zero-padded into the
+    // canonical window, and the march produces every column itself: no stash, no resize_edges_kernel, which cost the upscale cells 5-15 % of their time
+    // (profiles/r05_ab_edge_cost.txt).  A padded tap multiplies whatever lies beside the image by 0.0f and stands at the START or END of the ascending sum, so
+    // the sum is the reference's (+-0 aside, which packs to the same sample).
+    constexpr bool EIN = ring_edges_inside(Q, PX, TX, P);
+    constexpr int NWX = EIN ? P : F;
+    float wx[NWX][TX];
 #pragma unroll
-    for (int q = 0; q < F; ++q)
+    for (int q = 0; q < NWX; ++q)
 #pragma unroll
-        for (int j = 0; j < TX; ++j) asm("v_mov_b32 %0, %1" : "=v"(wx[q][j]) : "s"(wbits[q * TX + j]));
+        for (int j = 0; j < TX; ++j) asm("v_mov_b32 %0, %1" : "=v"(wx[q][j]) : "s"(wbits[(q % F) * TX + j]));
+    if constexpr (EIN) {
+        if (p.edge_in) {
+#pragma unroll
+            for (int o = 0; o < P; ++o) {
+                const int x = x0 + o;
+                if (x < p.dst_w && (x < p.cx0 || x >= p.cx1)) {   // (lane-varying: only the lanes at the image's sides)
+                    const int first = p.x_left[x] - (p.x_base + (x0 / Q) * PX + run_off(Q, PX, o, RC));   // host-checked: 0 <= first, first + count <= TX
+                    const int count = p.x_count[x];
+#pragma unroll
+                    for (int j = 0; j < TX; ++j) {
+                        const int t = j - first;
+                        float w = (t >= 0 && t < count) ? p.x_weight[(size_t)x * p.x_wtaps + min(max(t, 0), p.x_wtaps - 1)] : 0.0f;
+                        if constexpr (FMA) w = w * Sample<S16>::kInv;
+                        else if constexpr (exact_unpack_scaled(CH, S16)) w = w * kWeightScale;
+                        wx[o][j] = w;
+                    }
+                }
+            }
+        }
+    }
     static_assert(K % NB == 0 && TYM <= K + 1, "ring");
     const int32_t lane_off = (p.x_base + (grp0 + lane) * ((P / F) * PX)) * CS::BPP + sadj;
     const bool careful = __any(lane_off < 0);
@@ -873,9 +904,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(ring_min_wa
                 if (j >= 0 && j < TX) {
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
-                        if (j == 0) h[o][c] = wx[o % F][0] * u[c];
-                        else if constexpr (FMA) h[o][c] = __builtin_fmaf(wx[o % F][j], u[c], h[o][c]);
-                        else h[o][c] = h[o][c] + wx[o % F][j] * u[c];
+                        if (j == 0) h[o][c] = wx[o % NWX][0] * u[c];
+                        else if constexpr (FMA) h[o][c] = __builtin_fmaf(wx[o % NWX][j], u[c], h[o][c]);
+                        else h[o][c] = h[o][c] + wx[o % NWX][j] * u[c];
                     }
                 }
             }
@@ -910,12 +941,14 @@ hipError_t launch_ring_t(const RunParams &p, hipStream_t s, const char **name) {
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 4;
     const size_t lds = p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, Q, PX, TX, P, RC>::NW + 3) / 4 * 4) : 0;
     if (SRCP >= 0 && p.stash) return hipErrorInvalidValue;   // a convert in front: the edge columns come from the image
+    if (p.edge_in && !ring_edges_inside(Q, PX, TX, P)) return hipErrorInvalidValue;
     dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
     if (p.fma) resize_ring_kernel<CH, S16, Q, PX, TX, P, K, TYM, true, RC, SRCP><<<grid, 64 * bw, lds, s>>>(p);
     else resize_ring_kernel<CH, S16, Q, PX, TX, P, K, TYM, false, RC, SRCP><<<grid, 64 * bw, lds, s>>>(p);
     char srcs[24] = "";
     if (SRCP >= 0) snprintf(srcs, sizeof srcs, "src ch%d%s,", pixel_channels(SRCP < 0 ? 0 : SRCP), pixel_is16(SRCP < 0 ? 0 : SRCP) ? "u16" : "u8");
-    if (Q > PX) snprintf(g_kernel_name, sizeof g_kernel_name, "resize_up<%sch%d,%s,F%d,TX%d,P%d,%s,bw%d%s>", srcs, CH, S16 ? "u16" : "u8", Q, TX, P, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "");
+    if (Q > PX) snprintf(g_kernel_name, sizeof g_kernel_name, "resize_up<%sch%d,%s,F%d,TX%d,P%d,%s,bw%d%s%s>", srcs, CH, S16 ? "u16" : "u8", Q, TX, P, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "",
+                        p.edge_in && ring_edges_inside(Q, PX, TX, P) ? ",edges" : "");
     else snprintf(g_kernel_name, sizeof g_kernel_name, "resize_ring<%sch%d,%s,Q%d,PX%d,TX%d,P%d,K%d,%s,bw%d%s>", srcs, CH, S16 ? "u16" : "u8", Q, PX, TX, P, K, p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "");
     if (name) *name = g_kernel_name;
     return hipGetLastError();

@@ -149,5 +149,9 @@ def test_kernels_are_gfx950_wave64_without_scratch_spills(device_disassembly):
     funcs = device_disassembly
     hot = [k for k in funcs if "resize_stream_kernel" in k or "color_convert_kernel" in k or "resize_acc_kernel" in k or "resize_sym_kernel" in k or "resize_rows_kernel" in k or "resize_run_kernel" in k or "resize_ring_kernel" in k or "resize_edges_kernel" in k]
     assert hot
+    # one deliberate exception (r05): lanczos 2x on rgba compiles to 131 VGPRs = three waves per SIMD; held to the four-wave budget it spills five dwords
+    # and runs 3.3 % faster (kernels_run.hip ring_min_waves, profiles/r05_ab_reg_budgets.txt)
+    budgeted = {"resize_ring_kernelILi4ELb0ELi1ELi2ELi9ELi2ELi8ELi9E": 32}
     for k in hot:
-        assert funcs[k]["scratch"] == 0, "scratch traffic in " + k
+        allowed = max([v for sub, v in budgeted.items() if sub in k] + [0])
+        assert funcs[k]["scratch"] <= allowed, "scratch traffic in " + k

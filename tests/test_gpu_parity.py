@@ -1035,6 +1035,7 @@ def test_integer_upscales_on_the_accumulator_kernel_match_oracle(pixel, filt):
     from picha_amd.device import DeviceBatch, resize_batch
     import torch
     try:
+        set_opt("run", 2)   # (r05: the ring kernel with the clipped columns inside now takes these sizes first; this test is about the accumulator form)
         for f in (2, 3):
             sw, sh = 317, 93
             src = DeviceBatch(3, sw, sh, pixel).fill_random(7 + f)
@@ -1051,8 +1052,21 @@ def test_integer_upscales_on_the_accumulator_kernel_match_oracle(pixel, filt):
             assert not (names[1].startswith("resize_acc") and ",S0," in names[1]), names
             if f == 2 and filt != "triangle":      # triangle at 2x has 2 taps: the one-output accumulator kernel already serves it
                 assert names[0].startswith("resize_acc") and ",S0," in names[0], names
+        # ... and with the run / ring kernels allowed the same sizes come out of resize_up with the clipped columns inside, bit-exact too
+        set_opt("run", 1)
+        set_opt("up", 0)
+        for f in (2, 4):
+            sw, sh = 317, 93
+            src = DeviceBatch(3, sw, sh, pixel).fill_random(11 + f)
+            out = resize_batch(src, sw * f, sh * f, filter=filt)
+            torch.cuda.synchronize()
+            name = N.lib().picha_hip_last_kernel().decode()
+            for i in range(3):
+                exp = oracle_resize(src.image_host(i), sw * f, sh * f, filt or "cubic", 1.0 if filt else 0.70)
+                assert np.array_equal(out.image_host(i).pixels(), exp.pixels()), (name, f, i)
     finally:
         set_opt("up", 0)
+        set_opt("run", 0)
 
 
 def test_per_call_numerics_override_the_process_option():
