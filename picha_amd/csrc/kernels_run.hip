@@ -1029,13 +1029,13 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // defaults has 3 taps with the offsets rounded up, the 4-tap filters round down.  Ring-aliased downscales: lanczos 2x (9 x 9 taps
 // on a ring of 8).
 #define PICHA_UP_LIST_0(U) /* rgb */ U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4) U(1, 2, 9, 2, 0, 8, 9)
-#define PICHA_UP_LIST_1(U) /* rgba */ U(1, 2, 9, 2, 0, 8, 9) U(2, 1, 3, 2, 1, 4, 4) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 2, 0, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4)
+#define PICHA_UP_LIST_1(U) /* rgba */ U(1, 2, 9, 2, 0, 8, 9) U(2, 1, 3, 2, 1, 4, 4) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 2, 0, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4) U(4, 1, 4, 4, 0, 4, 4)
 #define PICHA_UP_LIST_2(U) /* grey */ U(1, 2, 9, 4, 0, 8, 9) U(1, 4, 17, 4, 0, 16, 17) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 3, 8, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(2, 1, 4, 8, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4)
 #define PICHA_UP_LIST_3(U) /* greya */ U(1, 2, 9, 4, 0, 8, 9) U(1, 4, 17, 2, 0, 16, 17) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 3, 8, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(2, 1, 4, 8, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4)
 #define PICHA_UP_LIST_4(U) /* r16 */ U(1, 2, 9, 4, 0, 8, 9) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 3, 8, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4)
 #define PICHA_UP_LIST_5(U) /* r16g16 */ U(1, 2, 9, 2, 0, 8, 9) U(2, 1, 3, 2, 1, 4, 4) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4)
 #define PICHA_UP_LIST_6(U) /* r16g16b16 */ U(1, 2, 9, 2, 0, 8, 9) U(2, 1, 3, 2, 1, 4, 4) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 2, 0, 4, 4)
-#define PICHA_UP_LIST_7(U) /* r16g16b16a16 */ U(1, 2, 9, 2, 0, 8, 9)   /* upscales: four outputs per lane measured 13 % slower than the accumulator form (0.49 against 0.56) */
+#define PICHA_UP_LIST_7(U) /* r16g16b16a16 */ U(1, 2, 9, 2, 0, 8, 9) U(2, 1, 3, 2, 1, 4, 4) U(2, 1, 4, 2, 0, 4, 4) U(4, 1, 4, 4, 0, 4, 4)   /* upscales: four outputs per lane measured 13 % slower than the accumulator form (0.49 against 0.56); two (r05), with the clipped columns inside: see capi.cpp */
 
 // Convert-in-front instantiations of the ring kernel (r04): V(SRCP, Q, PX, TX, P, RC, K, TYM) under the DESTINATION format's translation unit — the codec-edge
 // pairs of LAB.md 6.3 (-> jpeg: rgb / grey; -> webp: rgb / rgba; deep png -> 8 bit) at 2x with picha's defaults (3 taps, offsets rounded up) and at 4x.
