@@ -1117,9 +1117,9 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         for (int tx = tx_of[c]; tx <= tx_of[c] + 3 && !per_lane; ++tx)
             for (int pl0 : (up || (period == 2 && period_px == 3) ? order_up : kChannels[pixel] == 1 ? order1 : order2)) {
                 const int pl = opt_per_lane > 0 ? (int)opt_per_lane : pl0;   // "per_lane" names the run length outright
-                // (r05) 4x upscales of the four-channel formats: runs of four, which produce the clipped columns themselves, beat runs of eight + edge kernel
-                // (rgba -15 %, fma -27 %) and the accumulator form (r16g16b16a16 -13 %; its fma flavour stays there: +59 %) — profiles/r05_ab_up4.txt
-                if (up && !cv && opt_per_lane <= 0 && period == 4 && pl0 == 8 && kChannels[pixel] == 4 && up_kernel_supported(pixel, period, period_px, tx, 4, c, ring_rows, ay->host.taps)) continue;
+                // (r05) 4x upscales of the three- and four-channel formats: runs of four beat runs of eight
+                // (rgba -15 %, fma -27 %; rgb -5 % / -12 %; one- and two-channel formats +15 .. +43 %: profiles/r05_ab_up_survey.txt) and the accumulator form (r16g16b16a16 -13 %; its fma flavour stays there: +59 %) — profiles/r05_ab_up4.txt
+                if (up && !cv && opt_per_lane <= 0 && period == 4 && pl0 == 8 && kChannels[pixel] >= 3 && up_kernel_supported(pixel, period, period_px, tx, 4, c, ring_rows, ay->host.taps)) continue;
                 if (up && !cv && opt_run != 1 && period == 4 && pixel == PICHA_R16G16B16A16 && fma) continue;
                 if (pl <= 0 || pl % period || !(cv ? up_cv_kernel_supported(pixel, spixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : ring_mode ? up_kernel_supported(pixel, period, period_px, tx, pl, c, ring_rows, ay->host.taps) : (run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c) || (opt_run_ws != 2 && (run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c, -1, 1) || run_kernel_supported(pixel, period, period_px, tx, pl, nacc, c, -2, std::min(2, period))))))) continue;
                 per_lane = pl; ktaps = tx; ceil_off = c;

@@ -696,8 +696,8 @@ constexpr int ring_min_waves(int ch, bool s16, int q, int px, int tx, int p, int
 }
 
 // shapes of resize_ring_kernel that can produce the clipped edge columns themselves (EIN): upscales (more outputs than source pixels per period) whose
-// per-output weight sets are at most 24 registers
-__host__ __device__ constexpr bool ring_edges_inside(int q, int px, int tx, int p) { return q > px && p * tx <= 24; }
+// per-output weight sets are at most 32 registers
+__host__ __device__ constexpr bool ring_edges_inside(int q, int px, int tx, int p) { return q > px && p * tx <= 32; }
 
 // compile-time helpers of resize_ring_kernel: call f(integral_constant<i>) for the run-time i in [0, N) / for every i in [0, N)
 template <int N, int I = 0, typename Fn> __device__ __forceinline__ void switch_slot(int i, Fn &&f) {
@@ -1028,7 +1028,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // offsets inside a period rounded down / up, ring rows, most vertical taps.  Upscales (Q = 2, 4; PX = 1; K = 4): 2x with picha's
 // defaults has 3 taps with the offsets rounded up, the 4-tap filters round down.  Ring-aliased downscales: lanczos 2x (9 x 9 taps
 // on a ring of 8).
-#define PICHA_UP_LIST_0(U) /* rgb */ U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4) U(1, 2, 9, 2, 0, 8, 9)
+#define PICHA_UP_LIST_0(U) /* rgb */ U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4) U(1, 2, 9, 2, 0, 8, 9) U(4, 1, 4, 4, 0, 4, 4)
 #define PICHA_UP_LIST_1(U) /* rgba */ U(1, 2, 9, 2, 0, 8, 9) U(2, 1, 3, 2, 1, 4, 4) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 4, 2, 0, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4) U(4, 1, 4, 4, 0, 4, 4)
 #define PICHA_UP_LIST_2(U) /* grey */ U(1, 2, 9, 4, 0, 8, 9) U(1, 4, 17, 4, 0, 16, 17) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 3, 8, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(2, 1, 4, 8, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4)
 #define PICHA_UP_LIST_3(U) /* greya */ U(1, 2, 9, 4, 0, 8, 9) U(1, 4, 17, 2, 0, 16, 17) U(2, 1, 3, 4, 1, 4, 4) U(2, 1, 3, 8, 1, 4, 4) U(2, 1, 4, 4, 0, 4, 4) U(2, 1, 4, 8, 0, 4, 4) U(4, 1, 4, 8, 0, 4, 4)
