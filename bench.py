@@ -50,6 +50,9 @@ WORKLOADS = {
     "edge_deep_png_4k_rgba16_to_1080p_rgba": (32, 3840, 2160, "r16g16b16a16", 1920, 1080, {"convert": "rgba", "chain": True, "order": 1}),  # deep png -> 2x down -> 8-bit
     "up_960x540_rgba_to_1080p": (64, 960, 540, "rgba", 1920, 1080, {}),
     "up_960x540_r16_to_1080p": (64, 960, 540, "r16", 1920, 1080, {}),
+    # r05: upscales widened — deep formats on the ring kernel, 4x on runs of four, the clipped columns produced inside the march
+    "up_960x540_rgba16_to_1080p": (64, 960, 540, "r16g16b16a16", 1920, 1080, {}),
+    "up_480x270_rgba_to_1080p": (256, 480, 270, "rgba", 1920, 1080, {}),
     # r03: lanczos at even integer scales (ring-aliased vertical tables: the reference's ring is one row shorter than the window)
     "lanczos_4k_rgba_to_1080p": (64, 3840, 2160, "rgba", 1920, 1080, {"filter": "lanczos"}),   # 2x: the ring-in-registers kernel
     "lanczos_4k_rgb_to_480x270": (64, 3840, 2160, "rgb", 480, 270, {"filter": "lanczos"}),      # 8x: the accumulator kernel's row list (two-pass before r03)
