@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--prewarm-ms", type=float, default=60.0,
                     help="setup: run the path for this long before the W warm-up steps so the GPU has left its idle clocks "
                          "(a cold process needs ~9 launches / 25 ms to reach steady state, profiles/r01_launch_series.txt)")
-    ap.add_argument("--place", type=int, default=4,
+    ap.add_argument("--place", type=int, default=10,   # (r05: 4 until the history records — on a box with allocation history the fast placements can be candidates 7-10 only, profiles/r05_placement_history.txt)
                     help="setup: destination batches allocated and tried (the fastest is kept, the others freed); 1 = take the first allocation as it comes")
     ap.add_argument("--option", action="append", default=[], help="library knob key=value (e.g. row_chunks=4)")
     args = ap.parse_args()
