@@ -29,9 +29,9 @@ def test_bench_prints_one_json_line_with_roofline_and_cpu_baseline():
     assert d["config"]["parity_max_code_diff_vs_oracle_image0"] == 0          # bit-exact default flavour
     assert d["config"]["parity_max_code_diff_vs_oracle_first2_images_all_ranks"] == 0   # first two images per device
     assert d["config"]["ranks_seen"] == 1 and len(d["config"]["per_rank_ms"]) == 1 and len(d["config"]["per_rank_device"]) == 1
-    # setup: four destination candidates tried, the fastest kept, all of them in the line (r05); the second roof beside the first
+    # setup: ten destination candidates tried (four until the allocation-history records), the fastest kept, all of them in the line (r05); the second roof beside the first
     pl = d["config"]["destination_placement"]
-    assert len(pl["candidates"]) == 4 and 0 <= pl["kept"] < 4 and pl["candidates"][pl["kept"]][1] == min(c[1] for c in pl["candidates"])
+    assert len(pl["candidates"]) == 10 and 0 <= pl["kept"] < 10 and pl["candidates"][pl["kept"]][1] == min(c[1] for c in pl["candidates"])
     assert pl["candidates"][pl["kept"]][0] == d["config"]["dst_minus_src_mb"]
     assert d["roofline_valu"]["bound"] == "valu-issue" and 0 < d["roofline_valu"]["frac"] < 1 and d["roofline"]["tighter_roof"] in ("hbm", "valu-issue")
     r = d["roofline"]
