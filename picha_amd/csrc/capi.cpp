@@ -1138,7 +1138,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // >= 200 000 wave-rows; profiles/r05_ab_shu_rgb.txt, r05_ab_shu_rgb_defaults.txt)
     const bool shu_only = !ring_mode && xhl < 0 && !run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off) && !run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -1, 1);
     const long long wave_cols = (long long)n * (((d0.width + per_lane - 1) / per_lane + 63) / 64);
-    const bool short_ok = shu_only ? wave_cols * s0.height >= 200000 : period_px == 15 ? (ch == 1 && n >= 192) : (ch <= 2 && n >= 96);
+    // (r05: greya at 7.5x / 21 taps, a tie with the accumulator kernel in its plain form, wins in the shared-unpack form: 128 x 4K -> 512x288 0.579 -> 0.529 ms)
+    const bool greya_shu21 = ch == 2 && period_px == 15 && !fma && !ring_mode && opt_run_shu != 2 && opt_run_ws != 2 && opt_run_edges != 1 && n >= 96 &&
+                             run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -2, std::min(2, period));
+    const bool short_ok = shu_only ? wave_cols * s0.height >= 200000 : period_px == 15 ? ((ch == 1 && n >= 192) || greya_shu21) : (ch <= 2 && n >= 96);
     if (!ring_mode && xhl < 0 && opt_run == 0 && ktaps < 26 && !short_ok) RUN_GROUP_NA;
     // one phase's weights in SGPRs (r04): where instantiated — the 7.5x shapes, whose 2 x 30 lane-uniform weight registers held the
     // kernel at 3 waves per SIMD (profiles/r04_ab_run_ws.txt)

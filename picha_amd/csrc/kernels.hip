@@ -1,6 +1,9 @@
 // kernels.hip — launch interface of the gfx950 kernels.  The device code lives in kernels_impl.inc;
 // the single-output-per-lane span kernels (hundreds of instantiations) are compiled per pixel format
 // in kernels_span.hip so the build parallelises.
+#include <array>
+#include <map>
+#include <mutex>
 #include "kernels_impl.inc"
 
 namespace picha_hip {
@@ -91,10 +94,25 @@ hipError_t launch_resize_edges_kernel(int pixel, const RunParams &p, hipStream_t
     return hipErrorInvalidValue;
 }
 int run_kernel_resident_blocks(int pixel, const RunParams &p) {
+    // (r05) the answer depends on the kernel instantiation, the workgroup width and the device only: asked once per key (the planner asks on every call of the
+    // shapes whose chunk count is a whole round of resident workgroups; the occupancy query costs tens of microseconds of host time)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const std::array<int, 14> key = {dev, pixel, p.period, p.period_px, p.x_taps, p.x_per_lane, p.off_ceil, p.nacc, p.fma, p.xch ? (p.xch == 2 ? -2 : -p.x_base) : -1, p.wsgpr,
+                                     p.phase_shift > 0, p.block_waves, p.stash != nullptr};
+    static std::mutex mu;
+    static std::map<std::array<int, 14>, int> cache;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
     RunParams q = p;
     int n = 0;
     q.resident_query = &n;
     if (launch_resize_run_kernel(pixel, q, nullptr, nullptr) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    cache[key] = n;
     return n;
 }
 

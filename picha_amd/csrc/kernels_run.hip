@@ -301,11 +301,17 @@ template <int CH, bool S16, int Q, int PX, int TX, int P, int RC> struct RunShu 
     static constexpr int BPP = CH * Sample<S16>::kBytes;
     static constexpr int OWN = (P / Q) * PX;
     static constexpr int SPAN = run_off(Q, PX, P - 1, RC) + TX;
-    static constexpr int HR = SPAN - OWN;            // window pixels held by lane + 1
-    static constexpr int NF = HR * CH;               // floats taken from the neighbour = bytes of the wave's halo
+    static constexpr int HR = SPAN - OWN;            // window pixels held by the lanes behind this one
+    // (r05) windows that reach over TWO neighbours (lanczos thumbnails: 36 taps at 8x with two outputs per lane): lane + 1 gives all it owns, lane + 2 the rest
+    static constexpr int HR1 = HR < OWN ? HR : OWN, HR2 = HR - HR1;
+    static constexpr int NF = HR1 * CH;              // floats taken from lane + 1 (= what every lane leaves in its slots)
     static constexpr int NFC = (NF + 3) / 4;         // ... in 16-byte chunks
-    static constexpr int LANES = kWave + 1;          // slots per chunk: 64 lanes + the virtual lane behind the wave
-    static constexpr bool OK = !S16 && BPP < 4 && HR > 0 && HR <= OWN && NF <= kWave;
+    static constexpr int NF2 = HR2 * CH, NFC2 = (NF2 + 3) / 4;   // ... from lane + 2
+    static constexpr int VL = HR2 > 0 ? 2 : 1;       // virtual lanes behind the wave
+    static constexpr int LANES = kWave + VL;         // slots per chunk
+    // the samples behind the wave's run: one BYTE per lane (lane k: sample k) where they are at most 64, else one PIXEL per lane
+    static constexpr bool HALO_PX = HR * CH > kWave;
+    static constexpr bool OK = !S16 && BPP < 4 && HR > 0 && HR <= 2 * OWN && HR <= kWave && NFC * 4 <= OWN * CH + 3;
 };
 // PH (r04): TIME-PHASED STORES.  A finished output row is packed and kept in registers (up to kPhaseRows rows per lane); the wave stores
 // what it holds when the chip-wide 100 MHz counter (s_memrealtime) crosses a multiple of 2^phase_shift ticks — every wave of
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
     static_assert(!XCH || (X::OK && RC == 0), "neighbour exchange: dword pixels, halo within one lane's pixels");
     static_assert(WS >= 0 && WS <= Q, "phases with scalar weights");
     static_assert(!PH || C::WORDS, "phased stores: dword-sized pixels");
-    static_assert(!SHU || S::NFC * 4 <= S::OWN * CH, "shared unpack: whole chunks of own floats");
+    static_assert(!SHU || (S::NFC - 1) * 4 < S::OWN * CH, "shared unpack: chunks of own floats");
     constexpr int ODW = PH ? P * (C::BPP / 4) : 1;   // dwords of a lane's packed output row
     constexpr int NRAW = XCH ? X::NOWN + 1 : SHU ? CO::NW + 1 : C::NW;
     constexpr int NB = XCH ? PICHA_RUN_XNB : SHU ? 2 : (NRAW <= 16 ? PICHA_RUN_NB : 2);  // row buffers
@@ -379,7 +385,15 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
                                              : (grp0 + kWave) * X::OWN * C::BPP + 4 * (halo_k - X::NHL);
     __shared__ uint32_t halo_lds[XCH ? 4 * kWave : 1];
     // shared unpack: lane k fetches sample k of the NF behind the wave's run (the other lanes repeat the last one)
-    [[maybe_unused]] const int32_t shu_halo_off = (p.x_base + (grp0 + kWave) * S::OWN) * C::BPP + sadj + min(lane, S::NF - 1);
+    [[maybe_unused]] const int32_t shu_halo_off = S::HALO_PX ? (p.x_base + (grp0 + kWave) * S::OWN + min(lane, S::HR - 1)) * C::BPP + sadj
+                                                             : (p.x_base + (grp0 + kWave) * S::OWN) * C::BPP + sadj + min(lane, S::HR * CH - 1);
+    auto load_halo = [&](int row) __attribute__((always_inline)) -> uint32_t {
+        const uint32_t off = uint32_t(row * p.src_stride + shu_halo_off);
+        uint32_t v = __builtin_amdgcn_raw_buffer_load_b8(src_rs, off, 0, 0);
+        if constexpr (S::HALO_PX && C::BPP >= 2) v |= uint32_t(__builtin_amdgcn_raw_buffer_load_b8(src_rs, off + 1, 0, 0)) << 8;
+        if constexpr (S::HALO_PX && C::BPP >= 3) v |= uint32_t(__builtin_amdgcn_raw_buffer_load_b8(src_rs, off + 2, 0, 0)) << 16;
+        return v;
+    };
 
     const_i32_ptr yrange = (const_i32_ptr)(p.yrow_range);
     const_i32_ptr yrec = (const_i32_ptr)(p.yrow_rec);
@@ -406,7 +420,7 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
             t[X::NOWN] = __builtin_amdgcn_raw_buffer_load_b32(src_rs, uint32_t(row * p.src_stride + halo_off), 0, 0);
         } else if constexpr (SHU) {
             load_span<CO, false>(src_rs, row * p.src_stride + lane_off, t);
-            t[CO::NW] = __builtin_amdgcn_raw_buffer_load_b8(src_rs, uint32_t(row * p.src_stride + shu_halo_off), 0, 0);
+            t[CO::NW] = load_halo(row);
         } else {
             load_span<C, false>(src_rs, row * p.src_stride + lane_off, t);
         }
@@ -419,7 +433,7 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
         else if constexpr (SHU) {
             if (careful && row <= 0) {
                 load_span<CO, true>(src_rs, row * p.src_stride + lane_off, raw[k]);
-                raw[k][CO::NW] = __builtin_amdgcn_raw_buffer_load_b8(src_rs, uint32_t(row * p.src_stride + shu_halo_off), 0, 0);
+                raw[k][CO::NW] = load_halo(row);
             } else load_row(raw[k], row);
         } else {
             const int32_t off = row * p.src_stride + lane_off;
@@ -515,27 +529,45 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
         }
 #else
         uint32_t win[SHU ? CO::NWIN : XCH ? C::NW : (C::BROT ? C::NWIN : 1)];
-        [[maybe_unused]] float uown[SHU ? S::OWN * CH : 1], unext[SHU ? S::NFC * 4 : 1];
+        [[maybe_unused]] f32x4 *xl = reinterpret_cast<f32x4 *>(stash_lds) + wave * (S::NFC * S::LANES);   // (shared unpack: the wave's exchange slots)
+        [[maybe_unused]] float uown[SHU ? S::NFC * 4 > S::OWN * CH ? S::NFC * 4 : S::OWN * CH : 1], unext[SHU ? S::NFC * 4 : 1], unext2[SHU && S::HR2 > 0 ? S::NFC2 * 4 : 1];
         if constexpr (SHU) {
             rotate_span<CO>(cur, uint32_t(min(row, r1) * p.src_stride + lane_off) & 3u, win);
 #pragma unroll
             for (int q = 0; q < S::OWN; ++q) unpack_span_px<CO, CH, S16, FMA>(win, q, &uown[q * CH]);
-            const float uh = FMA ? float(cur[CO::NW]) : unpack_sample<S16>(cur[CO::NW]);
-            f32x4 *xl = reinterpret_cast<f32x4 *>(stash_lds) + wave * (S::NFC * S::LANES);
+#pragma unroll
+            for (int k = S::OWN * CH; k < S::NFC * 4; ++k) uown[k] = 0.0f;   // (the last chunk's padding)
 #pragma unroll
             for (int c = 0; c < S::NFC; ++c) {
-                f32x4 v = {uown[4 * c], uown[4 * c + 1], uown[4 * c + 2], uown[4 * c + 3]};   // (NFC * 4 <= OWN * CH + 3: checked below)
+                f32x4 v = {uown[4 * c], uown[4 * c + 1], uown[4 * c + 2], uown[4 * c + 3]};
                 xl[c * S::LANES + lane] = v;
             }
-            const int hk = min(lane, S::NF - 1);
-            reinterpret_cast<float *>(xl)[((hk >> 2) * S::LANES + kWave) * 4 + (hk & 3)] = uh;
+            if constexpr (S::HALO_PX) {   // the lane's halo PIXEL k (k < HR): pixel k % OWN of virtual lane 64 + k / OWN
+                const int hk = min(lane, S::HR - 1);
+                const int vl = hk >= S::OWN ? 1 : 0, hp = hk - vl * S::OWN;
+                float uh[CH];
+                const uint32_t hw[1] = {cur[CO::NW]};
+                unpack_span_px<EdgeCfg<CH, S16, 1>, CH, S16, FMA>(hw, 0, uh);
+#pragma unroll
+                for (int c = 0; c < CH; ++c) {
+                    const int f = hp * CH + c;
+                    reinterpret_cast<float *>(xl)[((f >> 2) * S::LANES + kWave + vl) * 4 + (f & 3)] = uh[c];
+                }
+            } else {
+                const float uh = FMA ? float(cur[CO::NW]) : unpack_sample<S16>(cur[CO::NW]);
+                const int hk = min(lane, S::HR * CH - 1);   // sample hk of the samples behind the run: float hk % (OWN * CH) of virtual lane 64 + hk / (OWN * CH)
+                const int vl = hk >= S::OWN * CH ? 1 : 0, f = hk - vl * S::OWN * CH;
+                reinterpret_cast<float *>(xl)[((f >> 2) * S::LANES + kWave + vl) * 4 + (f & 3)] = uh;
+            }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if constexpr (S::HR2 == 0) {   // (windows over two neighbours read theirs where the tap loop reaches them: 130 live floats otherwise)
 #pragma unroll
-            for (int c = 0; c < S::NFC; ++c) {
-                const f32x4 v = xl[c * S::LANES + lane + 1];
-                unext[4 * c] = v[0]; unext[4 * c + 1] = v[1]; unext[4 * c + 2] = v[2]; unext[4 * c + 3] = v[3];
+                for (int c = 0; c < S::NFC; ++c) {
+                    const f32x4 v = xl[c * S::LANES + lane + 1];
+                    unext[4 * c] = v[0]; unext[4 * c + 1] = v[1]; unext[4 * c + 2] = v[2]; unext[4 * c + 3] = v[3];
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -576,9 +608,29 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
             if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, qa, u);
             else unpack_span_px<C, CH, S16, FMA>(cur, qa, u);
 #else
+            if constexpr (SHU && S::HR2 > 0) {   // two neighbours: each one's floats are read when the tap loop reaches them (the compiler may not hoist the reads: "memory")
+                if (q == S::OWN) {
+                    asm volatile("" ::: "memory");
+#pragma unroll
+                    for (int c = 0; c < S::NFC; ++c) {
+                        const f32x4 v = xl[c * S::LANES + lane + 1];
+                        unext[4 * c] = v[0]; unext[4 * c + 1] = v[1]; unext[4 * c + 2] = v[2]; unext[4 * c + 3] = v[3];
+                    }
+                    asm volatile("" ::: "memory");
+                }
+                if (q == 2 * S::OWN) {
+#pragma unroll
+                    for (int c = 0; c < S::NFC2; ++c) {
+                        const f32x4 v = xl[c * S::LANES + lane + 2];
+                        unext2[4 * c] = v[0]; unext2[4 * c + 1] = v[1]; unext2[4 * c + 2] = v[2]; unext2[4 * c + 3] = v[3];
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // (the next row's writes stay behind these reads)
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
             if constexpr (SHU) {
 #pragma unroll
-                for (int c = 0; c < CH; ++c) u[c] = q < S::OWN ? uown[q * CH + c] : unext[(q - S::OWN) * CH + c];
+                for (int c = 0; c < CH; ++c) u[c] = q < S::OWN ? uown[q * CH + c] : q < 2 * S::OWN ? unext[(q - S::OWN) * CH + c] : unext2[(q - 2 * S::OWN < 0 ? 0 : q - 2 * S::OWN) * CH + c];
             }
             else if constexpr (C::BROT || XCH) unpack_span_px<C, CH, S16, FMA>(win, q, u);
             else unpack_span_px<C, CH, S16, FMA>(cur, q, u);
@@ -1015,10 +1067,10 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // Measured and not kept (profiles/r04_ab_run_ws.txt): both phases scalar (97 VGPRs, one short of a fifth wave per SIMD: +2 % exact, +12 % fma),
 // two row buffers instead of three (a tie), eight outputs per lane for the 30-tap shape (143 VGPRs once its 82-pixel window loop unrolls — see the
 // Makefile's -pragma-unroll-threshold; rolled, it indexed its registers dynamically and took 17 ms: -2.5 % exact at 12 chunks, +3 % fma).
-#define PICHA_RUNZ_LIST_0(Z) /* rgb */ Z(2, 15, 21, 2, 0, -2, 2) Z(1, 6, 17, 2, 0, -2, 1) Z(1, 8, 23, 2, 0, -2, 1)  /* (r05) shared unpack only; the plain forms at 7.5x / 21 taps (two or four outputs per lane, scalar phase weights or not) were -2 % exact, +7 % fma against resize_acc (r04, as r03 had found): not instantiated */
+#define PICHA_RUNZ_LIST_0(Z) /* rgb */ Z(2, 15, 21, 2, 0, -2, 2) Z(1, 6, 17, 2, 0, -2, 1) Z(1, 8, 23, 2, 0, -2, 1) Z(2, 15, 30, 2, 1, -2, 2) Z(2, 15, 31, 2, 0, -2, 2) /* (lanczos at 7.5x: windows over two neighbours.  Lanczos at 6x / 8x compiled to 100-120 VGPRs in this form but is ring-aliased in y: the accumulator kernel's row list serves it) */  /* (r05) shared unpack only; the plain forms at 7.5x / 21 taps (two or four outputs per lane, scalar phase weights or not) were -2 % exact, +7 % fma against resize_acc (r04, as r03 had found): not instantiated */
 #define PICHA_RUNZ_LIST_1(Z) /* rgba */ Z(1, 4, 11, 2, 0, 3, 0) Z(1, 4, 15, 2, 0, 5, 0) Z(1, 3, 8, 2, 0, 2, 0)
 #define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1) Z(2, 15, 30, 4, 1, -2, 2) Z(2, 15, 31, 4, 0, -2, 2) Z(2, 15, 21, 4, 0, -2, 2)
-#define PICHA_RUNZ_LIST_3(Z) /* greya */ Z(2, 15, 30, 2, 1, -1, 1) Z(2, 15, 31, 2, 0, -1, 1)
+#define PICHA_RUNZ_LIST_3(Z) /* greya */ Z(2, 15, 30, 2, 1, -1, 1) Z(2, 15, 31, 2, 0, -1, 1) Z(2, 15, 30, 2, 1, -2, 2) Z(2, 15, 31, 2, 0, -2, 2) Z(2, 15, 21, 2, 0, -2, 2)
 #define PICHA_RUNZ_LIST_4(Z) /* r16 */
 #define PICHA_RUNZ_LIST_5(Z) /* r16g16 */
 #define PICHA_RUNZ_LIST_6(Z) /* r16g16b16 */

@@ -41,7 +41,11 @@ template <int CH, bool S16, int P, int SX, int TX, bool XCH> constexpr int sym_n
 // epilogue_store in kernels_impl.inc): the finished pixel is packed to the resize's own sample type exactly as src/resize.cc:130
 // writes it, unpacked, channel-mapped and packed to p.epi_pixel (src/colorconvert.cc:143-150); dst_* describe THAT image.
 template <int CH, bool S16, int P, int SX, int TX, int SY, int TY, bool FMA, bool XCH = false, bool EPI = false>
+#ifdef PICHA_SYM_WAVES   // measurement builds: the register budget of N waves per SIMD
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(PICHA_SYM_WAVES, PICHA_SYM_WAVES))) void resize_sym_kernel(StreamParams p) {
+#else
 __global__ __launch_bounds__(256) void resize_sym_kernel(StreamParams p) {
+#endif
     using C = SpanCfg<CH, S16, P, SX, TX>;
     using X = XchCfg<CH, S16, P, SX, TX>;
     static_assert(!XCH || X::OK, "neighbour exchange: dword pixels, halo within one lane's pixels");

@@ -631,6 +631,10 @@ SHU_CASES = [   # pixel, source, destination, filter, filter scale: the shapes t
     ("rgb", (975, 121), (130, 16), "catmulrom", 0.70),      # ... ragged: 65 lanes
     ("rgb", (1920, 100), (320, 17), "mitchel", 0.70),       # 6x, 17 taps (period 1: every weight scalar)
     ("rgb", (2056, 90), (257, 11), "cubic", 0.70),          # 8x, 23 taps, an odd output width
+    ("rgb", (3840, 150), (512, 20), "lanczos", 1.0),        # 30 / 31 taps with two outputs per lane: the window reaches over TWO neighbours (lane + 1 gives all 15 pixels, lane + 2 eight)
+    ("rgb", (975, 60), (130, 8), "mitchel", 1.0),           # ... ragged: 65 lanes, the second virtual lane behind the wave in use
+    ("greya", (3840, 130), (512, 31), "lanczos", 1.0),      # greya, two neighbours, halo by bytes (46 samples)
+    ("greya", (1950, 77), (260, 20), "cubic", 0.70),        # greya 21 taps: one neighbour
 ]
 
 
@@ -657,13 +661,13 @@ def test_run_kernel_shared_unpack_matches_oracle(case):
                     got = picha.resizeSync(img, opts)
                     name = N.lib().picha_hip_last_kernel().decode()
                     if dw >= 8:
-                        assert name.startswith("resize_run<ch%d,u8,Q" % (1 if pixel == "grey" else 3)) and ",shu" in name and "+ resize_edges<" in name, name
+                        assert name.startswith("resize_run<ch%d,u8,Q" % N.PIXEL_CHANNELS[pixel]) and ",shu" in name and "+ resize_edges<" in name, name
                     assert max_code_diff(got, want) == 0, (case, rnd, chunks, work, bw, name)
                     if name.startswith("resize_run<"):
                         N.check(N.lib().picha_hip_set_option(b"run_shu", 2))
                         plain = picha.resizeSync(img, opts)
                         pname = N.lib().picha_hip_last_kernel().decode()
-                        assert ",shu" not in pname and pname.startswith("resize_run<" if pixel == "grey" else "resize_"), pname   # (rgb: no plain run kernel)
+                        assert ",shu" not in pname and pname.startswith("resize_run<" if pixel != "rgb" else "resize_"), pname   # (rgb: no plain run kernel)
                         assert max_code_diff(plain, got) == 0, (case, rnd, pname)
                         N.check(N.lib().picha_hip_set_option(b"run_shu", 1))
                         N.check(N.lib().picha_hip_set_option(b"run_edges", 1))
