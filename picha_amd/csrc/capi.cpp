@@ -1061,12 +1061,34 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         }
         if (!any) RUN_GROUP_NA;
     }
+    bool ylist = false;   // (r05) ring-aliased table: the march follows a list of source rows (shared-unpack form only)
     if (!up) {
         for (int na : {4, 6}) {
             const DeviceAxis::YRows *cand = nullptr;
             rc = get_yrows(ctx, ay, na, &cand);
             if (rc) return rc;
             if (cand->ok) { yr = cand; nacc = na; break; }
+        }
+        bool shu_shape = false;   // (only the shared-unpack shapes follow a row list; every other aliased table goes on to the ring kernel below)
+        for (int c = 0; c < 2 && !shu_shape; ++c) {
+            int xb0 = 0;
+            const int t0 = run_table_taps(ax->host, period, period_px, c, &xb0);
+            for (int tx = t0; t0 > 0 && tx <= t0 + 3 && !shu_shape; ++tx)
+                for (int pl : {2, 4, 8})
+                    for (int na : {4, 6}) shu_shape = shu_shape || run_kernel_supported(pixel, period, period_px, tx, pl, na, c, -2, std::min(2, period));
+        }
+        if (!yr && !cv && shu_shape && opt_run_shu != 2 && opt_run_ws != 2 && opt_run_edges != 1) {
+            bool row0_aliased = false;   // (the kernel's in-loop loads assume source row 0 sits at list position 0 only)
+            const AxisTaps &ty = ay->host;
+            for (int y = 0; y < d0.height; ++y)
+                if (ty.left[y] == 0 && ty.count[y] >= 2 && ty.eff[(size_t)y * ty.taps] == ty.count[y] - 1) row0_aliased = true;
+            for (int na : {4, 6}) {
+                if (row0_aliased) break;
+                const DeviceAxis::YRows *cand = nullptr;
+                rc = get_yrows(ctx, ay, na, &cand, true);
+                if (rc) return rc;
+                if (cand->ok && cand->src) { yr = cand; nacc = na; ylist = true; break; }
+            }
         }
     }
     if (!yr) {
@@ -1162,6 +1184,9 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     const bool shu_ok = !ring_mode && xhl < 0 && !cv && opt_run_shu != 2 && opt_run_ws != 2 && opt_run_edges != 1 &&
                         run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -2, std::min(2, period)) && (opt_run_shu == 1 || !fma || shu_only);
     if (shu_only && !shu_ok) RUN_GROUP_NA;
+    if (ylist && !shu_ok) RUN_GROUP_NA;
+    const int32_t *edge_range = nullptr;   // the edge kernel's source-row ranges are ROWS, not list positions
+    if (ylist) { rc = get_yrange(ctx, ay, &edge_range); if (rc) return rc; }
     // (r05) the upscale shapes of the ring kernel produce the clipped columns themselves from those columns' own weights, zero-padded into the canonical window
     // (kernels_run.hip EIN): no stash, no edge kernel — where every clipped column's taps lie inside its canonical window
     bool edges_inside = ring_mode && has_edges && (opt_run_edges == 0 || opt_run_edges == 3) && opt_run != 3 && up_edges_inside(period, period_px, ktaps, per_lane);
@@ -1266,7 +1291,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // enough for several phases; 2^12 ticks = 41 us measured best on cfg5 (profiles/r04_ab_run_phase.txt)
     if (xhl >= 0 && opt_run_phase >= 0) p.phase_shift = opt_run_phase > 0 ? (int)std::min(20L, opt_run_phase) : (s0.height >= 3 * d0.height && (long long)n * s0.height >= 20000 ? 12 : 0);
     if (ring_mode) { p.yrow_range = up_range; p.y_left = ay->left; p.y_info = ay->y_info; p.ring_rows = ring_rows; }
-    else { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.nacc = nacc; }
+    else { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.yrow_src = ylist ? yr->src : nullptr; p.nacc = nacc; }
     p.cx0 = rt->c0; p.cx1 = rt->c1;
     if (opt_run == 3) { p.cx0 = 0; p.cx1 = d0.width; }  // measurement only: no edge pass (the edge columns come out wrong)
     p.edge_rows = edge_rows;
@@ -1325,7 +1350,11 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     };
     auto edges_all = [&](hipStream_t es) {
         hipError_t e = hipSuccess;
-        for (int done = 0; done < n && e == hipSuccess; done += 65535) e = launch_resize_edges_kernel(pixel, slice(done, std::min(n - done, 65535)), es);
+        for (int done = 0; done < n && e == hipSuccess; done += 65535) {
+            RunParams q = slice(done, std::min(n - done, 65535));
+            if (ylist) q.yrow_range = edge_range;
+            e = launch_resize_edges_kernel(pixel, q, es);
+        }
         return e;
     };
     // launch form: the plain grid (measured r03 on cfg3b: item list +3 %, persistent +30 %; the edge kernel follows either way)
@@ -1355,7 +1384,11 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
             const int m = std::min(n - done, 65535);
             const RunParams q = slice(done, m);
             e = ring_mode ? launch_resize_up_kernel(pixel, q, s, &g_last_kernel) : launch_resize_run_kernel(pixel, q, s, &g_last_kernel);
-            if (e == hipSuccess) e = launch_resize_edges_kernel(pixel, q, s);
+            if (e == hipSuccess) {
+                RunParams qe = q;
+                if (ylist) qe.yrow_range = edge_range;
+                e = launch_resize_edges_kernel(pixel, qe, s);
+            }
             if (e != hipSuccess) return fail_launch(e);
             done += m;
         }

@@ -257,6 +257,7 @@ struct RunParams {
     const float *x_canon;
     int fma;
     const int32_t *yrow_rec, *yrow_range;  // the accumulator kernel's per-source-row records
+    const int32_t *yrow_src;               // (r05, shared-unpack form) ring-aliased tables: records / ranges are positions in this LIST of source rows (FusedParams::yrow_src); nullptr: position == row
     int nacc;
     int rows_per_chunk, n_chunks;
     int block_waves;  // waves per workgroup (1..4): adjacent column strips of the same rows

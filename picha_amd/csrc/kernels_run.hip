@@ -399,6 +399,10 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
     const_i32_ptr yrec = (const_i32_ptr)(p.yrow_rec);
     const int r0 = yrange[2 * y0];
     const int r1 = yrange[2 * (y1 - 1) + 1];
+    // ring-aliased vertical tables (r05; lanczos at integer scales, as in resize_acc_kernel): r / r0 / r1 are positions in the list p.yrow_src of source rows, in which the
+    // row an aliased first tap reads appears once more ahead of its window; src_of() gives the source row (identity without a list).  Host-checked: position 0 is row 0's only place.
+    const_i32_ptr ysrc = (const_i32_ptr)(p.yrow_src);
+    auto src_of = [&](int i) __attribute__((always_inline)) { return ysrc != nullptr ? int(ysrc[i]) : i; };
 
     float acc[NACC][P][CH];
 #pragma unroll
@@ -428,7 +432,7 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
     uint32_t raw[NB][NRAW];
 #pragma unroll
     for (int k = 0; k < NB - 1; ++k) {
-        const int row = min(r0 + k, r1);
+        const int row = src_of(min(r0 + k, r1));
         if constexpr (XCH) { load_row(raw[k], row); }
         else if constexpr (SHU) {
             if (careful && row <= 0) {
@@ -532,7 +536,7 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
         [[maybe_unused]] f32x4 *xl = reinterpret_cast<f32x4 *>(stash_lds) + wave * (S::NFC * S::LANES);   // (shared unpack: the wave's exchange slots)
         [[maybe_unused]] float uown[SHU ? S::NFC * 4 > S::OWN * CH ? S::NFC * 4 : S::OWN * CH : 1], unext[SHU ? S::NFC * 4 : 1], unext2[SHU && S::HR2 > 0 ? S::NFC2 * 4 : 1];
         if constexpr (SHU) {
-            rotate_span<CO>(cur, uint32_t(min(row, r1) * p.src_stride + lane_off) & 3u, win);
+            rotate_span<CO>(cur, uint32_t(src_of(min(row, r1)) * p.src_stride + lane_off) & 3u, win);
 #pragma unroll
             for (int q = 0; q < S::OWN; ++q) unpack_span_px<CO, CH, S16, FMA>(win, q, &uown[q * CH]);
 #pragma unroll
@@ -572,7 +576,7 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
         } else
-        if constexpr (C::BROT) rotate_span<C>(cur, uint32_t(min(row, r1) * p.src_stride + lane_off) & 3u, win);
+        if constexpr (C::BROT) rotate_span<C>(cur, uint32_t(src_of(min(row, r1)) * p.src_stride + lane_off) & 3u, win);
         if constexpr (XCH && PICHA_RUN_ABLATE == 3) {
 #pragma unroll
             for (int k = 0; k < C::NW; ++k) win[k] = cur[k % X::NOWN];
@@ -723,7 +727,7 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
 #pragma unroll
         for (int k = 0; k < NB; ++k) {
 #if PICHA_RUN_ABLATE != 2
-            load_row(raw[(k + NB - 1) % NB], max(XCH ? 0 : 1, min(r + k + NB - 1, r1)));
+            load_row(raw[(k + NB - 1) % NB], src_of(max(XCH ? 0 : 1, min(r + k + NB - 1, r1))));
 #endif
             process_row(raw[k], r + k);
         }
@@ -1067,7 +1071,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // Measured and not kept (profiles/r04_ab_run_ws.txt): both phases scalar (97 VGPRs, one short of a fifth wave per SIMD: +2 % exact, +12 % fma),
 // two row buffers instead of three (a tie), eight outputs per lane for the 30-tap shape (143 VGPRs once its 82-pixel window loop unrolls — see the
 // Makefile's -pragma-unroll-threshold; rolled, it indexed its registers dynamically and took 17 ms: -2.5 % exact at 12 chunks, +3 % fma).
-#define PICHA_RUNZ_LIST_0(Z) /* rgb */ Z(2, 15, 21, 2, 0, -2, 2) Z(1, 6, 17, 2, 0, -2, 1) Z(1, 8, 23, 2, 0, -2, 1) Z(2, 15, 30, 2, 1, -2, 2) Z(2, 15, 31, 2, 0, -2, 2) /* (lanczos at 7.5x: windows over two neighbours.  Lanczos at 6x / 8x compiled to 100-120 VGPRs in this form but is ring-aliased in y: the accumulator kernel's row list serves it) */  /* (r05) shared unpack only; the plain forms at 7.5x / 21 taps (two or four outputs per lane, scalar phase weights or not) were -2 % exact, +7 % fma against resize_acc (r04, as r03 had found): not instantiated */
+#define PICHA_RUNZ_LIST_0(Z) /* rgb */ Z(2, 15, 21, 2, 0, -2, 2) Z(1, 6, 17, 2, 0, -2, 1) Z(1, 8, 23, 2, 0, -2, 1) Z(2, 15, 30, 2, 1, -2, 2) Z(2, 15, 31, 2, 0, -2, 2) Z(1, 8, 33, 2, 0, -2, 1) Z(1, 6, 25, 2, 0, -2, 1) /* (lanczos: windows over two neighbours; at 6x / 8x the vertical table is ring-aliased: the march follows the row list) */  /* (r05) shared unpack only; the plain forms at 7.5x / 21 taps (two or four outputs per lane, scalar phase weights or not) were -2 % exact, +7 % fma against resize_acc (r04, as r03 had found): not instantiated */
 #define PICHA_RUNZ_LIST_1(Z) /* rgba */ Z(1, 4, 11, 2, 0, 3, 0) Z(1, 4, 15, 2, 0, 5, 0) Z(1, 3, 8, 2, 0, 2, 0)
 #define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1) Z(2, 15, 30, 4, 1, -2, 2) Z(2, 15, 31, 4, 0, -2, 2) Z(2, 15, 21, 4, 0, -2, 2)
 #define PICHA_RUNZ_LIST_3(Z) /* greya */ Z(2, 15, 30, 2, 1, -1, 1) Z(2, 15, 31, 2, 0, -1, 1) Z(2, 15, 30, 2, 1, -2, 2) Z(2, 15, 31, 2, 0, -2, 2) Z(2, 15, 21, 2, 0, -2, 2)
