@@ -1165,6 +1165,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
                              run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -2, std::min(2, period));
     const bool short_ok = shu_only ? wave_cols * s0.height >= 200000 : period_px == 15 ? ((ch == 1 && n >= 192) || greya_shu21) : (ch <= 2 && n >= 96);
     if (!ring_mode && xhl < 0 && opt_run == 0 && ktaps < 26 && !short_ok) RUN_GROUP_NA;
+    if (ylist && opt_run == 0 && wave_cols * s0.height < 200000) RUN_GROUP_NA;   // (the row-list shapes were measured on batches: lanczos thumbnails of 64-128 4K images)
     // one phase's weights in SGPRs (r04): where instantiated — the 7.5x shapes, whose 2 x 30 lane-uniform weight registers held the
     // kernel at 3 waves per SIMD (profiles/r04_ab_run_ws.txt)
     const int wsgpr = !ring_mode && xhl < 0 && opt_run_ws != 2 && run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -1, 1) ? 1 : 0;

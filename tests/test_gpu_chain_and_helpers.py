@@ -637,6 +637,8 @@ SHU_CASES = [   # pixel, source, destination, filter, filter scale: the shapes t
     ("greya", (1950, 77), (260, 20), "cubic", 0.70),        # greya 21 taps: one neighbour
     ("rgb", (3840, 264), (480, 33), "lanczos", 1.0),        # 8x lanczos: 33 taps over two neighbours, and a ring-aliased vertical table — the march follows the row list
     ("rgb", (1920, 300), (320, 50), "lanczos", 1.0),        # 6x lanczos: 25 taps, five waves per row
+    ("grey", (3840, 264), (480, 33), "lanczos", 1.0),       # grey 8x lanczos: four outputs per lane, one neighbour, row list
+    ("greya", (1920, 300), (320, 50), "lanczos", 1.0),      # greya 6x lanczos: two neighbours, halo by bytes, row list
 ]
 
 
@@ -669,7 +671,7 @@ def test_run_kernel_shared_unpack_matches_oracle(case):
                         N.check(N.lib().picha_hip_set_option(b"run_shu", 2))
                         plain = picha.resizeSync(img, opts)
                         pname = N.lib().picha_hip_last_kernel().decode()
-                        assert ",shu" not in pname and pname.startswith("resize_run<" if pixel != "rgb" else "resize_"), pname   # (rgb: no plain run kernel)
+                        assert ",shu" not in pname and pname.startswith("resize_run<" if pixel != "rgb" and sw % dw else "resize_"), pname   # (rgb, and the row-list shapes: no plain run kernel)
                         assert max_code_diff(plain, got) == 0, (case, rnd, pname)
                         N.check(N.lib().picha_hip_set_option(b"run_shu", 1))
                         N.check(N.lib().picha_hip_set_option(b"run_edges", 1))
