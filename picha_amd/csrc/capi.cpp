@@ -1190,7 +1190,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     if (ylist) { rc = get_yrange(ctx, ay, &edge_range); if (rc) return rc; }
     // (r05) the upscale shapes of the ring kernel produce the clipped columns themselves from those columns' own weights, zero-padded into the canonical window
     // (kernels_run.hip EIN): no stash, no edge kernel — where every clipped column's taps lie inside its canonical window
-    bool edges_inside = ring_mode && has_edges && (opt_run_edges == 0 || opt_run_edges == 3) && opt_run != 3 && up_edges_inside(period, period_px, ktaps, per_lane);
+    bool edges_inside = has_edges && (opt_run_edges == 0 || opt_run_edges == 3) && opt_run != 3 &&
+                        (ring_mode ? up_edges_inside(period, period_px, ktaps, per_lane) : (!cv && xhl >= 0 && wsgpr == 0 && run_xch_edges_inside(ktaps, per_lane)));
     if (edges_inside) {
         const AxisTaps &tx = ax->host;
         auto offg = [&](int x) { return (x / period) * period_px + ((x % period) * period_px + ceil_off * (period - 1)) / period; };

@@ -298,6 +298,7 @@ hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s
 // ring-in-registers kernel (integer upscales: period = the factor, period_px = 1, ring 4; ring-aliased downscales: ring = the
 // reference's): yrow_rec unused; yrow_range: per output row {first source row needed by it or any later row, last row so far}
 bool up_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int off_ceil, int ring_rows, int y_taps);
+constexpr bool run_xch_edges_inside(int taps, int per_lane) { return per_lane * taps <= 32; }   // == run_edges_inside for the neighbour-exchange forms (kernels_run.hip)
 constexpr bool up_edges_inside(int period, int period_px, int taps, int per_lane) { return period > period_px && per_lane * taps <= 32; }   // == ring_edges_inside (kernels_run.hip)
 hipError_t launch_resize_up_kernel(int pixel, const RunParams &p, hipStream_t s, const char **kernel_name);
 bool up_cv_kernel_supported(int pixel, int src_pixel, int period, int period_px, int taps, int per_lane, int off_ceil, int ring_rows, int y_taps);  // p.cv_on forms

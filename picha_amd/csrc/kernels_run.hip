@@ -313,6 +313,8 @@ template <int CH, bool S16, int Q, int PX, int TX, int P, int RC> struct RunShu 
     static constexpr bool HALO_PX = HR * CH > kWave;
     static constexpr bool OK = !S16 && BPP < 4 && HR > 0 && HR <= 2 * OWN && HR <= kWave && NFC * 4 <= OWN * CH + 3;
 };
+// shapes of resize_run_kernel that can produce the clipped edge columns themselves (EIN): the neighbour-exchange forms with all weights in lane registers
+__host__ __device__ constexpr bool run_edges_inside(int xhl, int ws, int tx, int p) { return xhl >= 0 && ws == 0 && p * tx <= 32; }
 // PH (r04): TIME-PHASED STORES.  A finished output row is packed and kept in registers (up to kPhaseRows rows per lane); the wave stores
 // what it holds when the chip-wide 100 MHz counter (s_memrealtime) crosses a multiple of 2^phase_shift ticks — every wave of
 // every workgroup in the same few microseconds — or when it holds kPhaseRows rows, or at the end of its chunk.  Why: in cfg5's march the
@@ -364,14 +366,38 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
     int32_t wbits[Q * TX];
 #pragma unroll
     for (int j = 0; j < Q * TX; ++j) wbits[j] = xc[j];
-    float wx[Q][TX];
+    // EIN (r05, as in resize_ring_kernel): the neighbour-exchange shapes hold their weights in lane registers anyway — one set per OUTPUT of the lane (<= 32 registers)
+    // lets the lanes at the image's sides take the clipped columns' own zero-padded weights, and the march produces every column itself (cfg5: the edge kernel was 2 % of the launch)
+    constexpr bool EIN = run_edges_inside(XHL, WS, TX, P);
+    constexpr int NWX = EIN ? P : Q;
+    float wx[NWX][TX];
 #pragma unroll
-    for (int q = 0; q < Q; ++q)
+    for (int q = 0; q < NWX; ++q)
 #pragma unroll
         for (int j = 0; j < TX; ++j) {
-            if (q < Q - WS) asm("v_mov_b32 %0, %1" : "=v"(wx[q][j]) : "s"(wbits[q * TX + j]));
+            if (EIN || q < Q - WS) asm("v_mov_b32 %0, %1" : "=v"(wx[q][j]) : "s"(wbits[(q % Q) * TX + j]));
             else wx[q][j] = __int_as_float(wbits[q * TX + j]);   // stays scalar: an SGPR operand of its products
         }
+    if constexpr (EIN) {
+        if (p.edge_in) {
+#pragma unroll
+            for (int o = 0; o < P; ++o) {
+                const int x = x0 + o;
+                if (x < p.dst_w && (x < p.cx0 || x >= p.cx1)) {   // (lane-varying: only the lanes at the image's sides)
+                    const int first = p.x_left[x] - (p.x_base + (x0 / Q) * PX + run_off(Q, PX, o, RC));   // host-checked: 0 <= first, first + count <= TX
+                    const int count = p.x_count[x];
+#pragma unroll
+                    for (int j = 0; j < TX; ++j) {
+                        const int t = j - first;
+                        float w = (t >= 0 && t < count) ? p.x_weight[(size_t)x * p.x_wtaps + min(max(t, 0), p.x_wtaps - 1)] : 0.0f;
+                        if constexpr (FMA) w = w * Sample<S16>::kInv;
+                        else if constexpr (exact_unpack_scaled(CH, S16)) w = w * kWeightScale;
+                        wx[o][j] = w;
+                    }
+                }
+            }
+        }
+    }
     // the lane's window starts at x_base + PX * (x0 / Q): x0 is a multiple of P, P of Q
     // (neighbour exchange: the lane's OWN pixels, XHL pixels into the window; x_base == -XHL is host-checked)
     const int32_t lane_off = XCH ? (grp0 + lane) * X::OWN * C::BPP : (p.x_base + (grp0 + lane) * ((P / Q) * PX)) * C::BPP + sadj;
@@ -645,9 +671,9 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
                 if (j >= 0 && j < TX) {
 #pragma unroll
                     for (int c = 0; c < CH; ++c) {
-                        if (j == 0) h[o][c] = wx[o % Q][0] * u[c];
-                        else if constexpr (FMA) h[o][c] = __builtin_fmaf(wx[o % Q][j], u[c], h[o][c]);
-                        else h[o][c] = h[o][c] + wx[o % Q][j] * u[c];
+                        if (j == 0) h[o][c] = wx[o % NWX][0] * u[c];
+                        else if constexpr (FMA) h[o][c] = __builtin_fmaf(wx[o % NWX][j], u[c], h[o][c]);
+                        else h[o][c] = h[o][c] + wx[o % NWX][j] * u[c];
                     }
                 }
             }
@@ -1017,6 +1043,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
     const int bw = p.block_waves >= 1 && p.block_waves <= 4 ? p.block_waves : 4;
     using SH = RunShu<CH, S16, Q, PX, TX, P, RC>;
     if (XHL == -2 && p.stash) return hipErrorInvalidValue;   // shared unpack: the clipped columns come from the image
+    if (p.edge_in && !run_edges_inside(XHL, WS, TX, P)) return hipErrorInvalidValue;
     const size_t lds = XHL == -2 ? sizeof(float) * 4 * bw * SH::NFC * SH::LANES   // the exchange slots
                      : p.stash ? sizeof(uint32_t) * bw * 2 * kWave * ((RunCfg<CH, S16, Q, PX, TX, P, RC>::NW + 3) / 4 * 4) : 0;   // the stash staging of the edge lanes
     if (p.resident_query) {
@@ -1036,6 +1063,7 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
     if (XHL == -2) snprintf(form, sizeof form, ",shu");
     if (WS > 0) snprintf(form + strlen(form), sizeof form - strlen(form), ",ws%d", WS);
     if (PH > 0) snprintf(form + strlen(form), sizeof form - strlen(form), ",phased%d", p.phase_shift);
+    if (p.edge_in) snprintf(form + strlen(form), sizeof form - strlen(form), ",edges");
     snprintf(g_kernel_name, sizeof g_kernel_name, "resize_run<ch%d,%s,Q%d,PX%d,TX%d,P%d,NACC%d,%s,bw%d%s%s%s>", CH, S16 ? "u16" : "u8", Q, PX, TX, P, NACC,
              p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "", form, work_suffix(p.work));
     if (name) *name = g_kernel_name;

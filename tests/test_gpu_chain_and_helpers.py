@@ -543,17 +543,18 @@ def test_run_kernel_neighbour_exchange_matches_oracle(case):
     img = rand_image(rng, sw, sh, pixel, pad=int(rng.choice([0, 8, 16])))
     want = oracle_resize(img, dw, dh, filt, fscale)
     opts = {"width": dw, "height": dh, "filter": filt, "filterScale": fscale}
-    keys = (b"run_xch", b"row_chunks", b"work", b"numerics", b"block_waves", b"run_phase")
+    keys = (b"run_xch", b"row_chunks", b"work", b"numerics", b"block_waves", b"run_phase", b"run_edges")
     expect = r"resize_run<ch4,%s,Q1,PX%d,TX%d,P2,NACC\d,(exact|fma),bw\d,xch%d" % ("u16" if pixel.startswith("r16") else "u8", px, taps, hl)
     try:
         N.check(N.lib().picha_hip_set_option(b"run_xch", 1))
         for chunks, work, bw in ((0, 0, 0), (1, 3, 0), (3, 1, 1), (2, 2, 2), (5, 0, 4)):
+            N.check(N.lib().picha_hip_set_option(b"run_edges", 2 if chunks == 3 else 0))   # (the edge kernel reading the image, or — r05, auto — the clipped columns inside the march)
             N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
             N.check(N.lib().picha_hip_set_option(b"work", work))
             N.check(N.lib().picha_hip_set_option(b"block_waves", bw))
             got = picha.resizeSync(img, opts)
             name = N.lib().picha_hip_last_kernel().decode()
-            assert re.match(expect, name) and "+ resize_edges<" in name, name
+            assert re.match(expect, name) and ("+ resize_edges<" in name) != (",edges" in name), name   # (r05: the clipped columns inside the march, or the edge kernel)
             assert max_code_diff(got, want) == 0, (case, chunks, work, bw, name)
         for k in keys[1:]:
             N.check(N.lib().picha_hip_set_option(k, 0))
@@ -709,7 +710,7 @@ def test_edge_columns_from_the_stash_or_the_image_match_oracle(case, edges):
             N.check(N.lib().picha_hip_set_option(b"numerics", numerics))
             got = picha.resizeSync(img, opts)
             name = N.lib().picha_hip_last_kernel().decode()
-            inside = edges == 3 and name.startswith("resize_up<") and ",edges" in name
+            inside = edges == 3 and name.startswith(("resize_up<", "resize_run<")) and ",edges" in name
             if name.startswith(("resize_up<", "resize_ring<", "resize_run<")):   # (odd sizes: the stash forms may decline and leave the geometry to another kernel)
                 assert inside != ("+ resize_edges<" in name), name
             if edges == 3 and dw == 2 * sw:

@@ -646,7 +646,7 @@ def test_kernel_selection_for_the_baseline_workloads():
         ("rgba", 384, 216, 192, 108, {"filter": "cubic"}, "resize_stream<ch4,u8,P2,SX2,TX7,SY2,TY7"),     # cfg2, 7 taps
         ("grey", 3840, 216, 512, 51, {"filter": "lanczos"}, "resize_run<ch1,u8,Q2,PX15,TX30,P4,NACC"),   # cfg3b (x: 7.5x = period 2 / 15 pixels, y: 4.2x): run kernel (r03; was the row-staged kernel)
         ("grey", 3584, 216, 512, 51, {"filter": "lanczos"}, "resize_rows<src ch1u8,ch1,u8,P2,S7,TX32"),   # 7x, 28 taps: no run-kernel instantiation, the row-staged kernel
-        ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_run<ch4,u16,Q1,PX4,TX15,P2,NACC4,exact,bw2,xch5> + resize_edges<4 columns>"),   # cfg5: neighbour-exchange run kernel, wave-uniform weights (r04; r03: resize_acc<...,xch>)
+        ("r16g16b16a16", 768, 432, 192, 108, {"filter": "mitchel"}, "resize_run<ch4,u16,Q1,PX4,TX15,P2,NACC4,exact,bw2,xch5,edges>"),   # cfg5: neighbour-exchange run kernel (r04; r03: resize_acc<...,xch>), the clipped columns inside the march (r05)
         ("r16", 320, 180, 640, 360, {}, "resize_up<ch1,u16,F2,TX3,P8,exact"),                            # 2x upscale: register-ring kernel (r03)
         ("rgb", 320, 180, 640, 360, {}, "resize_up<ch3,u8,F2,TX3,P4,exact"),
         ("r16", 320, 180, 960, 540, {}, "resize_acc<ch1,u16,P4,S0,TX"),                                  # 3x upscale (not bit-periodic): accumulator kernel, four outputs per lane (r03)
