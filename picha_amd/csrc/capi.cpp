@@ -1785,6 +1785,14 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
                 chunks = std::max<long long>(chunks, (d0.height + rows - 1) / rows);
             }
             chunks = std::max<long long>(1, std::min<long long>(chunks, std::max(1, opt_chunks > 0 ? d0.height : d0.height / 16)));
+            if (opt_chunks <= 0 && !sym) {
+                // (r05) batches of SMALL images on the streaming kernel (cfg1: 256 x 640x480 -> 320x240): one whole round of resident workgroups instead of
+                // three or four ragged ones — 15 -> 4 chunks: -8 % (fma -10 %); only where a chunk stays short (<= 128 output rows): profiles/r05_ab_cfg1_chunks.txt
+                const long long per_chunk = n * ((cx->groups + 255) / 256);
+                const int resident = stream_kernel_resident_blocks(pixel, p);
+                const long long round = resident > 0 ? resident / per_chunk : 0;
+                if (round >= 2 && round < chunks && (d0.height + round - 1) / round <= 128) chunks = round;
+            }
             // small launches (a single image): chunks of down to 4 rows for about 3000 waves (profiles/r03_ab_small_launches.txt)
             if (opt_chunks <= 0 && n * col_waves * chunks < 3000)
                 chunks = std::max(chunks, std::min<long long>(std::max(1, d0.height / 4), (3000 + n * col_waves - 1) / (n * col_waves)));

@@ -194,9 +194,11 @@ struct StreamParams {
     // resize_sym_kernel, colour-convert epilogue (r04; as FusedParams::epi_*): dst_* describe the converted image
     int epi_on, epi_pixel;
     float epi_r, epi_g, epi_b;
+    int *resident_query;   // (r05, resize_stream_kernel) host pointer; set: launch nothing, report how many workgroups of this kernel the device holds at once
 };
 bool stream_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int rot);
 hipError_t launch_resize_stream_kernel(int pixel, const StreamParams &p, hipStream_t s, const char **kernel_name);
+int stream_kernel_resident_blocks(int pixel, const StreamParams &p);   // workgroups of the chosen instantiation the device holds at once (cached per shape)
 bool stream_dpp_supported(int pixel, int sx, int tx, int sy, int ty);
 bool sym_kernel_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty, int xch = 0);
 bool sym_epi_supported(int pixel, int per_lane, int sx, int tx, int sy, int ty);   // colour-convert epilogue instantiation

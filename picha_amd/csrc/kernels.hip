@@ -93,6 +93,25 @@ hipError_t launch_resize_edges_kernel(int pixel, const RunParams &p, hipStream_t
     }
     return hipErrorInvalidValue;
 }
+int stream_kernel_resident_blocks(int pixel, const StreamParams &p) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    const std::array<int, 14> key = {dev, pixel, p.x_per_lane, p.x_step, p.x_taps, p.y_step, p.y_taps, p.fma, p.rot != 0, -77, 0, 0, 0, 0};
+    static std::mutex mu;
+    static std::map<std::array<int, 14>, int> cache;
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) return it->second;
+    }
+    StreamParams q = p;
+    int n = 0;
+    q.resident_query = &n;
+    if (launch_resize_stream_kernel(pixel, q, nullptr, nullptr) != hipSuccess) return 0;
+    std::lock_guard<std::mutex> lk(mu);
+    cache[key] = n;
+    return n;
+}
 int run_kernel_resident_blocks(int pixel, const RunParams &p) {
     // (r05) the answer depends on the kernel instantiation, the workgroup width and the device only: asked once per key (the planner asks on every call of the
     // shapes whose chunk count is a whole round of resident workgroups; the occupancy query costs tens of microseconds of host time)
