@@ -164,6 +164,12 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "run_ws"     (r04) the weights of one phase of the period in SGPRs (the 7.5x shapes: four waves per SIMD): 0 = auto, 1 = wherever instantiated, 2 = never
  *   "run_phase"  (r04) time-phased stores of the neighbour-exchange form (finished rows wait in registers until a chip-wide 100 MHz counter crosses a
  *                phase boundary): 0 = auto (launches with >= 3 source rows per output row and >= 20 000 image-rows), -1 = off, n = phases of 2^n ticks
+ *   "run_shu"    (r05) its shared-unpack form for 8-bit grey / greya / rgb (a lane converts only the pixels its window starts with; the rest arrive converted
+ *                from the next one or two lanes through LDS; also follows the row list of ring-aliased vertical tables): 0 = auto (where measured faster), 1 =
+ *                wherever instantiated, 2 = never
+ *   "run_edges"  (r05) the columns whose windows an image edge clips: 0 / 3 = auto (produced inside the march where its weights are lane registers — integer
+ *                upscales, the neighbour-exchange form — else by a small second kernel reading a stash or the image, whichever measured faster), 1 = second
+ *                kernel from the stash the march writes, 2 = second kernel from the image
  *   "run_round"  its window offsets inside a period: 0 = auto (the rounding with the shorter window), 1 = down, 2 = up
  *                ("run" = 3 is a measurement aid: the run kernel WITHOUT its edge columns — those come out wrong)
  *   "fuse"       picha_hip_convert_resize*: 0 = one fused kernel where it exists and was measured faster (default: every
