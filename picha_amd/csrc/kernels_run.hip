@@ -1101,8 +1101,8 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
 // Makefile's -pragma-unroll-threshold; rolled, it indexed its registers dynamically and took 17 ms: -2.5 % exact at 12 chunks, +3 % fma).
 #define PICHA_RUNZ_LIST_0(Z) /* rgb */ Z(2, 15, 21, 2, 0, -2, 2) Z(1, 6, 17, 2, 0, -2, 1) Z(1, 8, 23, 2, 0, -2, 1) Z(2, 15, 30, 2, 1, -2, 2) Z(2, 15, 31, 2, 0, -2, 2) Z(1, 8, 33, 2, 0, -2, 1) Z(1, 6, 25, 2, 0, -2, 1) /* (lanczos: windows over two neighbours; at 6x / 8x the vertical table is ring-aliased: the march follows the row list) */  /* (r05) shared unpack only; the plain forms at 7.5x / 21 taps (two or four outputs per lane, scalar phase weights or not) were -2 % exact, +7 % fma against resize_acc (r04, as r03 had found): not instantiated */
 #define PICHA_RUNZ_LIST_1(Z) /* rgba */ Z(1, 4, 11, 2, 0, 3, 0) Z(1, 4, 15, 2, 0, 5, 0) Z(1, 3, 8, 2, 0, 2, 0)
-#define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1) Z(2, 15, 30, 4, 1, -2, 2) Z(2, 15, 31, 4, 0, -2, 2) Z(2, 15, 21, 4, 0, -2, 2) Z(1, 8, 33, 4, 0, -2, 1) Z(1, 6, 25, 4, 0, -2, 1)
-#define PICHA_RUNZ_LIST_3(Z) /* greya */ Z(2, 15, 30, 2, 1, -1, 1) Z(2, 15, 31, 2, 0, -1, 1) Z(2, 15, 30, 2, 1, -2, 2) Z(2, 15, 31, 2, 0, -2, 2) Z(2, 15, 21, 2, 0, -2, 2) Z(1, 8, 33, 2, 0, -2, 1) Z(1, 6, 25, 2, 0, -2, 1)
+#define PICHA_RUNZ_LIST_2(Z) /* grey */ Z(2, 15, 30, 4, 1, -1, 1) Z(2, 15, 31, 4, 0, -1, 1) Z(2, 15, 21, 4, 0, -1, 1) Z(2, 15, 30, 4, 1, -2, 2) Z(2, 15, 31, 4, 0, -2, 2) Z(2, 15, 21, 4, 0, -2, 2) Z(1, 8, 33, 4, 0, -2, 1) Z(1, 6, 25, 4, 0, -2, 1) Z(1, 8, 23, 4, 0, -2, 1) Z(1, 6, 17, 4, 0, -2, 1)
+#define PICHA_RUNZ_LIST_3(Z) /* greya */ Z(2, 15, 30, 2, 1, -1, 1) Z(2, 15, 31, 2, 0, -1, 1) Z(2, 15, 30, 2, 1, -2, 2) Z(2, 15, 31, 2, 0, -2, 2) Z(2, 15, 21, 2, 0, -2, 2) Z(1, 8, 33, 2, 0, -2, 1) Z(1, 6, 25, 2, 0, -2, 1) Z(1, 8, 23, 2, 0, -2, 1) Z(1, 6, 17, 2, 0, -2, 1)
 #define PICHA_RUNZ_LIST_4(Z) /* r16 */
 #define PICHA_RUNZ_LIST_5(Z) /* r16g16 */
 #define PICHA_RUNZ_LIST_6(Z) /* r16g16b16 */

@@ -640,6 +640,8 @@ SHU_CASES = [   # pixel, source, destination, filter, filter scale: the shapes t
     ("rgb", (1920, 300), (320, 50), "lanczos", 1.0),        # 6x lanczos: 25 taps, five waves per row
     ("grey", (3840, 264), (480, 33), "lanczos", 1.0),       # grey 8x lanczos: four outputs per lane, one neighbour, row list
     ("greya", (1920, 300), (320, 50), "lanczos", 1.0),      # greya 6x lanczos: two neighbours, halo by bytes, row list
+    ("grey", (2056, 90), (257, 11), "cubic", 0.70),         # grey 8x, 23 taps, four outputs per lane, an odd width
+    ("greya", (1920, 100), (320, 17), "mitchel", 0.70),     # greya 6x, 17 taps
 ]
 
 
