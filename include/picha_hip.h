@@ -170,6 +170,8 @@ int picha_hip_device_arch(char *buf, size_t len);
  *   "run_edges"  (r05) the columns whose windows an image edge clips: 0 / 3 = auto (produced inside the march where its weights are lane registers — integer
  *                upscales, the neighbour-exchange form — else by a small second kernel reading a stash or the image, whichever measured faster), 1 = second
  *                kernel from the stash the march writes, 2 = second kernel from the image
+ *   "edge_rows"  (r05) most output rows per block of that second kernel (1 .. 64; 0 = 64, what 8 KB of LDS hold): 16 .. 64 measured within 1 %
+ *   "run_efuse"  (r05) measurement builds only (-DPICHA_RUN_EFUSE): 1 = the edge pass as extra workgroups inside the march's grid (measured slower; ignored otherwise)
  *   "run_round"  its window offsets inside a period: 0 = auto (the rounding with the shorter window), 1 = down, 2 = up
  *                ("run" = 3 is a measurement aid: the run kernel WITHOUT its edge columns — those come out wrong)
  *   "fuse"       picha_hip_convert_resize*: 0 = one fused kernel where it exists and was measured faster (default: every

@@ -965,6 +965,9 @@ long g_opt_run = 0;   // run kernel (periodic tap tables, kernels_run.hip): 0 au
 long g_opt_run_round = 0;  // its window offsets inside a period: 0 auto (the shorter window), 1 rounded down, 2 rounded up
 long g_opt_run_xch = 0;    // its neighbour-exchange form (dword-sized pixels, integer scales; r04): 0 auto, 1 wherever instantiated, 2 never
 long g_opt_run_ws = 0;     // weights of one phase of the period in SGPRs (r04): 0 auto, 1 wherever instantiated, 2 never
+long g_opt_edge_rows = 0;   // most output rows per block of the edge kernel (0: 64, what its 2048 LDS floats allow): smaller blocks = more, shorter waves
+#define PICHA_EFUSE_DEFAULT(o) ((o) == 1)   /* auto = off until measured */
+long g_opt_run_efuse = 0;  // (r05, third session) the edge blocks inside the march's grid (RunParams::edge_fused; cfg3b's shared-unpack shape, plain grids): 0 auto, 1 on, 2 off
 long g_opt_run_shu = 0;    // shared unpack through LDS (r05; 8-bit grey / greya, kernels_run.hip RunShu): 0 auto (wherever instantiated), 1 the same, 2 never
 long g_opt_run_edges = 0;  // where resize_edges_kernel takes the clipped columns' windows from (it follows the march on the same stream either way): 0 auto, 1 a stash the march
                            // writes (r03 form; the image where the form has no stash), 2 the image, 3 = 0.  Auto = the measured winner (profiles/r05_ab_run_edges_shu.txt): the
@@ -995,10 +998,10 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     *used = false;
     const picha_image &s0 = src[0], &d0 = dst[0];
     const int pixel = d0.pixel, spixel = s0.pixel;   // the format the kernel computes in / the format it loads
-    long opt_run, opt_run_round, opt_numerics, opt_chunks, opt_per_lane, opt_work, opt_work_tail, opt_work_tail_div, opt_bw, opt_run_xch, opt_run_ws, opt_run_phase, opt_run_edges, opt_run_shu;
+    long opt_run, opt_run_round, opt_numerics, opt_chunks, opt_per_lane, opt_work, opt_work_tail, opt_work_tail_div, opt_bw, opt_run_xch, opt_run_ws, opt_run_phase, opt_run_edges, opt_run_shu, opt_run_efuse;
     {
         std::lock_guard<std::mutex> lk(g_opt_mu);
-        opt_run_xch = g_opt_run_xch; opt_run_ws = g_opt_run_ws; opt_run_phase = g_opt_run_phase; opt_run_edges = g_opt_run_edges; opt_run_shu = g_opt_run_shu;
+        opt_run_xch = g_opt_run_xch; opt_run_ws = g_opt_run_ws; opt_run_phase = g_opt_run_phase; opt_run_edges = g_opt_run_edges; opt_run_shu = g_opt_run_shu; opt_run_efuse = g_opt_run_efuse;
         if (g_opt_xch != 0 && opt_run_xch == 0) opt_run_xch = 2;   // "xch" = 1 / 2 asks for / rules out the exchange forms of the symmetric-table and accumulator kernels: not this one
         opt_run = g_opt_run; opt_run_round = g_opt_run_round; opt_numerics = tl_numerics >= 0 ? tl_numerics : g_opt_numerics; opt_chunks = g_opt_row_chunks; opt_per_lane = g_opt_per_lane;
         opt_work = g_opt_work; opt_work_tail = std::max(0L, std::min(1000L, g_opt_work_tail)); opt_work_tail_div = std::max(1L, g_opt_work_tail_div);
@@ -1224,6 +1227,8 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
         }
     }
     int edge_rows = 0;
+    std::vector<int> edge_first, edge_last;   // per output row: first source row needed by it or any later row / last row needed so far (the march's range table)
+    int edge_fixed_floats = 0, edge_col_floats = 0, edge_ytaps = 0, edge_lds_floats = 0;
     {   // blocks of the edge pass (kernels_run.hip, edge_pass): x weights + y weights + horizontal sums <= 2048 floats (kEdgeFloats)
         const int ncol = std::max(1, std::max(rt->c0, d0.width - rt->c1));   // one side per wave
         const int txe = (ktaps + 3) / 4 * 4;
@@ -1240,11 +1245,13 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
             for (int ya = 0; ya < d0.height; ya += rows) m = std::max(m, last[std::min(d0.height, ya + rows) - 1] - first[ya] + 1);
             return m;
         };
-        int er = std::min(64, d0.height);
+        int er = std::min(g_opt_edge_rows >= 1 && g_opt_edge_rows <= 64 ? (int)g_opt_edge_rows : 64, d0.height);
         auto floats = [&](int rows) { return ncol * txe + rows * ty.taps + ncol * ch * max_rows(rows); };
         while (er > 1 && floats(er) > 2048) --er;
         if (floats(er) > 2048) RUN_GROUP_NA;
         edge_rows = er;
+        edge_lds_floats = floats(er);
+        edge_first = first; edge_last = last; edge_fixed_floats = ncol * txe; edge_col_floats = ncol * ch; edge_ytaps = ty.taps;
     }
     RunParams p{};
     long long sp = 0, dp = 0;
@@ -1296,7 +1303,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     else { p.yrow_rec = yr->rec; p.yrow_range = yr->range; p.yrow_src = ylist ? yr->src : nullptr; p.nacc = nacc; }
     p.cx0 = rt->c0; p.cx1 = rt->c1;
     if (opt_run == 3) { p.cx0 = 0; p.cx1 = d0.width; }  // measurement only: no edge pass (the edge columns come out wrong)
-    p.edge_rows = edge_rows;
+    p.edge_rows = edge_rows; p.edge_lds_floats = edge_lds_floats;
     p.x_left = ax->left; p.x_count = ax->count; p.x_weight = ax->weight; p.x_wtaps = ax->host.taps;
     p.y_count = ay->count; p.y_eff = ay->eff; p.y_weight = ay->weight; p.y_taps = ay->host.taps;
     const int col_waves = (p.x_groups + 63) / 64;
@@ -1361,6 +1368,22 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     };
     // launch form: the plain grid (measured r03 on cfg3b: item list +3 %, persistent +30 %; the edge kernel follows either way)
     const int work_mode = !ring_mode && (opt_work == 1 || opt_work == 2) ? (int)opt_work : 0;
+    // (r05, third session) cfg3b's shape carries its edge blocks in the march's own grid (kernels_run.hip, run_edges_fused): no second kernel
+    if (!work_mode && !ring_mode && shu && p.edge_image && !ylist && !cv && opt_run != 3 && kRunEfuseBuilt && PICHA_EFUSE_DEFAULT(opt_run_efuse) && pixel == PICHA_GREY && period == 2 && period_px == 15 &&
+        ktaps == 30 && per_lane == 4 && p.block_waves >= 2 && p.rows_per_chunk >= 1) {
+        // the edge blocks start at the march's chunk boundaries, not at multiples of edge_rows: size their sub-blocks for THOSE starts
+        auto fits = [&](int er) {
+            for (int y0 = 0; y0 < d0.height; y0 += p.rows_per_chunk)
+                for (int ya = y0, y1 = std::min(d0.height, y0 + p.rows_per_chunk); ya < y1; ya += er) {
+                    const int yb = std::min(y1, ya + er);
+                    if (edge_fixed_floats + (yb - ya) * edge_ytaps + edge_col_floats * (edge_last[yb - 1] - edge_first[ya] + 1) > 2048) return false;
+                }
+            return true;
+        };
+        int er = edge_rows;
+        while (er > 1 && !fits(er)) --er;
+        if (fits(er)) { p.edge_fused = 1; p.edge_rows = er; }
+    }
     if (work_mode) {
         std::shared_ptr<const DeviceCtx::ItemList> il;
             std::shared_ptr<const DeviceCtx::Queue> qhold;
@@ -1386,7 +1409,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
             const int m = std::min(n - done, 65535);
             const RunParams q = slice(done, m);
             e = ring_mode ? launch_resize_up_kernel(pixel, q, s, &g_last_kernel) : launch_resize_run_kernel(pixel, q, s, &g_last_kernel);
-            if (e == hipSuccess) {
+            if (e == hipSuccess && !p.edge_fused) {
                 RunParams qe = q;
                 if (ylist) qe.yrow_range = edge_range;
                 e = launch_resize_edges_kernel(pixel, qe, s);
@@ -1395,7 +1418,7 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
             done += m;
         }
     }
-    if (p.stash || p.edge_image) {
+    if ((p.stash || p.edge_image) && !p.edge_fused) {
         static thread_local char name[192];
         snprintf(name, sizeof name, "%s + resize_edges<%d columns>", g_last_kernel ? g_last_kernel : "", p.cx0 + (d0.width - p.cx1));
         g_last_kernel = name;
@@ -2525,6 +2548,8 @@ int picha_hip_set_option(const char *key, long value) {
     if (strcmp(key, "run_ws") == 0) { g_opt_run_ws = value; return PICHA_OK; }
     if (strcmp(key, "run_phase") == 0) { g_opt_run_phase = value; return PICHA_OK; }
     if (strcmp(key, "run_shu") == 0) { g_opt_run_shu = value; return PICHA_OK; }
+    if (strcmp(key, "run_efuse") == 0) { g_opt_run_efuse = value; return PICHA_OK; }
+    if (strcmp(key, "edge_rows") == 0) { g_opt_edge_rows = value; return PICHA_OK; }
     if (strcmp(key, "run_edges") == 0) { if (value < 0 || value > 3) return fail(PICHA_ERR_ARGUMENT, "run_edges: 0..3"); g_opt_run_edges = value; return PICHA_OK; }
     if (strcmp(key, "up") == 0) { g_opt_up = value; return PICHA_OK; }
     if (strcmp(key, "work") == 0) { g_opt_work = value; return PICHA_OK; }
@@ -2561,6 +2586,8 @@ long picha_hip_get_option(const char *key) {
     if (strcmp(key, "run_ws") == 0) return g_opt_run_ws;
     if (strcmp(key, "run_phase") == 0) return g_opt_run_phase;
     if (strcmp(key, "run_shu") == 0) return g_opt_run_shu;
+    if (strcmp(key, "run_efuse") == 0) return g_opt_run_efuse;
+    if (strcmp(key, "edge_rows") == 0) return g_opt_edge_rows;
     if (strcmp(key, "run_edges") == 0) return g_opt_run_edges;
     if (strcmp(key, "up") == 0) return g_opt_up;
     if (strcmp(key, "work") == 0) return g_opt_work;

@@ -288,6 +288,11 @@ struct RunParams {
     int wsgpr;       // phases of the period whose weights stay in SGPRs (0 .. period)
     int edge_image;  // 1: resize_edges_kernel reads the edge columns' windows from the image, not from a stash
     int edge_in;     // 1 (r05, resize_ring_kernel shapes with up_edges_inside()): the march takes the clipped columns' own weights and produces them itself — no edge kernel
+    // (r05, third session) the edge blocks INSIDE the march's grid: per (row chunk, image) two more workgroups at blockIdx.x >= edge_bx0 (one wave each, one per side)
+    // run the edge pass over the chunk's rows reading the image, next in dispatch order to the march's workgroups of the same rows; the march leaves the clipped
+    // columns alone (its side lanes store pixel by pixel).  Plain grids only; shapes: run_edges_fused() in kernels_run.hip
+    int edge_fused, edge_bx0;
+    int edge_lds_floats;   // LDS floats a block of the edge kernel needs (host-computed for edge_rows; 0: kEdgeFloats) — smaller blocks, more of them resident
     int phase_shift; // > 0 (neighbour-exchange shapes): time-phased stores — finished rows wait in registers until s_memrealtime >> phase_shift changes
     // colour convert in front of an integer upscale (r04, resize_ring_kernel / resize_edges_kernel): the source images are in cv_src_pixel, every window
     // pixel goes through src/colorconvert.cc:136-152 (unpack, channel map, pack = the intermediate image's quantised samples) in registers and is then
@@ -295,6 +300,12 @@ struct RunParams {
     int cv_on, cv_src_pixel;
     float cv_r, cv_g, cv_b;
 };
+// the in-grid edge blocks are a measurement build (-DPICHA_RUN_EFUSE): measured slower than the edge kernel in the reference flavour (profiles/r05_ab_edge_blocks.txt)
+#ifdef PICHA_RUN_EFUSE
+constexpr bool kRunEfuseBuilt = true;
+#else
+constexpr bool kRunEfuseBuilt = false;
+#endif
 bool run_kernel_supported(int pixel, int period, int period_px, int taps, int per_lane, int nacc, int off_ceil, int xhl = -1, int wsgpr = 0);
 hipError_t launch_resize_run_kernel(int pixel, const RunParams &p, hipStream_t s, const char **kernel_name);
 // ring-in-registers kernel (integer upscales: period = the factor, period_px = 1, ring 4; ring-aliased downscales: ring = the

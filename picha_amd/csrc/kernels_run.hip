@@ -140,7 +140,7 @@ __device__ __forceinline__ void convert_span_px(const uint32_t *raw, int q, floa
 // the march already paid (141-283 MB for cfg3b: 0.03-0.07 ms, alone or as an epilogue of the march's waves, whatever the form
 // of the loop — r03, profiles/r03_ab_run_kernel.txt); the march has those bytes in registers.
 constexpr int kEdgeFloats = 2048;
-template <int CH, bool S16, int TXE, int SRCP = -1>
+template <int CH, bool S16, int TXE, int SRCP = -1, int GOV = 0>
 __device__ __forceinline__ void edge_pass(const RunParams &p, __amdgpu_buffer_rsrc_t stash_rs, int st_stride, int st_org, __amdgpu_buffer_rsrc_t dst_rs,
                                           int lane, float *lds, int xa0, int na, int y0, int y1) {
     constexpr int SCH = SRCP < 0 ? CH : pixel_channels(SRCP < 0 ? 0 : SRCP);
@@ -176,7 +176,7 @@ __device__ __forceinline__ void edge_pass(const RunParams &p, __amdgpu_buffer_rs
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- A: horizontal sums, one column after the other; G groups of 64 source rows (one window per lane) in flight ----
         // (no run-time integer division anywhere in this kernel: its expansion uses v_fmac, which the ISA test reserves for the fma flavour)
-        constexpr int G = E::NW <= 12 ? 4 : 2;
+        constexpr int G = GOV > 0 ? GOV : E::NW <= 12 ? 4 : 2;   // (GOV: the pass inside the march's kernel must stay under the march's register count)
         for (int c = 0; c < ncol; ++c) {
             const int32_t bo = xl[xa0 + c] * E::BPP - st_org;   // window start inside the stash row: >= 0 (host-checked containment)
             const uint32_t phase = uint32_t(bo) & 3u;
@@ -270,6 +270,22 @@ __global__ __launch_bounds__(64) void resize_edges_kernel(RunParams p) {
     edge_pass<CH, S16, TXE>(p, stash_rs, int(st_stride), p.stash_org[side], dst_rs, lane, edge_lds, xa0, na, y0, y1);
 }
 
+// (r05, third session) the same pass as one wave of a workgroup INSIDE the march's grid (RunParams::edge_fused): always from the image
+template <int CH, bool S16, int TXE>
+__device__ __forceinline__ void edge_block_from_image(const RunParams &p, float *lds, int lane, int img, int side, int y0, int y1) {
+    const int xa0 = side == 0 ? 0 : p.cx1;
+    const int na = side == 0 ? p.cx0 : p.dst_w - p.cx1;
+    if (y0 >= y1 || na <= 0) return;
+    uint8_t *dbase = uniform_ptr(p.dst_tab ? static_cast<uint8_t *>(p.dst_tab[img]) : p.dst + img * p.dst_pitch);
+    const __amdgpu_buffer_rsrc_t dst_rs = __builtin_amdgcn_make_buffer_rsrc(dbase, 0, p.dst_bytes, 0x00020000);
+    const uint8_t *sbase = uniform_ptr(p.src_tab ? static_cast<const uint8_t *>(p.src_tab[img]) : p.src + img * p.src_pitch);
+    const int sadj = int(reinterpret_cast<uintptr_t>(sbase) & 3u);
+    const __amdgpu_buffer_rsrc_t img_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(sbase) - sadj, 0, (p.src_bytes + sadj + 3u) & ~3u, 0x00020000);
+    edge_pass<CH, S16, TXE, -1, 1>(p, img_rs, p.src_stride, -sadj, dst_rs, lane, lds, xa0, na, y0, y1);
+}
+// shapes of resize_run_kernel that carry the edge blocks in their own grid: cfg3b's shared-unpack shape (grey 7.5x, 30 taps, four outputs per lane)
+__host__ __device__ constexpr bool run_edges_fused(int ch, bool s16, int q, int px, int tx, int p, int xhl) { return kRunEfuseBuilt && ch == 1 && !s16 && q == 2 && px == 15 && tx == 30 && p == 4 && xhl == -2; }
+
 // XHL >= 0 (r04): NEIGHBOUR EXCHANGE for dword-sized pixels.  A lane loads only the (P / Q) * PX pixels it owns — the wave reads one
 // contiguous run per row, no byte is requested twice (cfg5's plain form asks for every source byte 4.75 times and is bound by the L1's
 // request rate, profiles/r03_cfg5_before_rocprofv3_summary.txt) — and takes the XHL pixels in front of them from lane - 1 and the
@@ -347,6 +363,16 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int bw = __builtin_amdgcn_readfirstlane(blockDim.x >> 6);
+    constexpr bool EFUSE = run_edges_fused(CH, S16, Q, PX, TX, P, XHL);
+    if constexpr (EFUSE) {
+        if (p.edge_fused && int(blockIdx.x) >= p.edge_bx0) {   // (workgroup-uniform) the two edge blocks of this (row chunk, image): wave 0 works, in the workgroup's exchange slots
+            extern __shared__ __attribute__((aligned(16))) float efuse_lds[];
+            if (wave == 0)
+                edge_block_from_image<CH, S16, (TX + 3) / 4 * 4>(p, efuse_lds, lane, blockIdx.z, int(blockIdx.x) - p.edge_bx0, blockIdx.y * p.rows_per_chunk,
+                                                                 min(p.dst_h, (int(blockIdx.y) + 1) * p.rows_per_chunk));
+            return;
+        }
+    }
     auto run_item = [&](int bx, int y0, int y1, int img) __attribute__((always_inline)) {
     const int grp0 = (bx * bw + wave) * kWave;
     if (grp0 * P >= p.dst_w) return;
@@ -732,7 +758,20 @@ __global__ __launch_bounds__(256) PICHA_RUN_WAVES_ATTR void resize_run_kernel(Ru
 #else
                     if (y >= y0 && y < y1)
 #endif
+                    {
+                        bool side_lane = false;
+                        if constexpr (EFUSE) side_lane = p.edge_fused && (x0 < p.cx0 || x0 + P > p.cx1);
+                        if (side_lane) {   // (edge blocks in the grid: the clipped columns are theirs, in no order with this store)
+#pragma unroll
+                            for (int q = 0; q < P; ++q)
+                                if (x0 + q >= p.cx0 && x0 + q < p.cx1) {
+                                    uint32_t pw[2];
+                                    pack_px_words<CH, S16, FMA>(acc[a][q], pw);
+                                    store_px_words<CH, S16>(dst_rs, uint32_t(y * p.dst_stride + (x0 + q) * C::BPP), pw);
+                                }
+                        } else
                         store_lane_outputs<C, CH, S16, P, FMA>(acc[PICHA_RUN_ABLATE == 1 ? 0 : a], dst_rs, uint32_t(y * p.dst_stride + x0 * C::BPP), x0, p.dst_w);
+                    }
                 }
 #pragma unroll
                 for (int o = 0; o < P; ++o)
@@ -1056,14 +1095,21 @@ hipError_t launch_run_t(const RunParams &p, hipStream_t s, const char **name) {
     }
     dim3 grid((p.x_groups + 64 * bw - 1) / (64 * bw), p.n_chunks, p.n_images);
     if (p.work.items) grid = dim3(p.work.queue ? (unsigned)p.n_chunks : 8u * (unsigned)p.work.items_per_xcd, 1, 1);
-    if (p.fma) resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true, RC, XHL, WS, PH><<<grid, 64 * bw, lds, s>>>(p);
-    else resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false, RC, XHL, WS, PH><<<grid, 64 * bw, lds, s>>>(p);
+    RunParams q = p;
+    if (p.edge_fused) {   // two edge blocks per (row chunk, image) behind the march's; they work in the workgroup's exchange slots (kEdgeFloats floats)
+        if (!run_edges_fused(CH, S16, Q, PX, TX, P, XHL) || p.work.items || !p.edge_image || lds < sizeof(float) * kEdgeFloats) return hipErrorInvalidValue;
+        q.edge_bx0 = (int)grid.x;
+        grid.x += 2;
+    }
+    if (p.fma) resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, true, RC, XHL, WS, PH><<<grid, 64 * bw, lds, s>>>(q);
+    else resize_run_kernel<CH, S16, Q, PX, TX, P, NACC, false, RC, XHL, WS, PH><<<grid, 64 * bw, lds, s>>>(q);
     char form[40] = "";
     if (XHL >= 0) snprintf(form, sizeof form, ",xch%d", XHL);
     if (XHL == -2) snprintf(form, sizeof form, ",shu");
     if (WS > 0) snprintf(form + strlen(form), sizeof form - strlen(form), ",ws%d", WS);
     if (PH > 0) snprintf(form + strlen(form), sizeof form - strlen(form), ",phased%d", p.phase_shift);
     if (p.edge_in) snprintf(form + strlen(form), sizeof form - strlen(form), ",edges");
+    if (p.edge_fused) snprintf(form + strlen(form), sizeof form - strlen(form), ",edgeblocks");
     snprintf(g_kernel_name, sizeof g_kernel_name, "resize_run<ch%d,%s,Q%d,PX%d,TX%d,P%d,NACC%d,%s,bw%d%s%s%s>", CH, S16 ? "u16" : "u8", Q, PX, TX, P, NACC,
              p.fma ? "fma" : "exact", bw, RC ? ",ceil" : "", form, work_suffix(p.work));
     if (name) *name = g_kernel_name;
@@ -1229,7 +1275,7 @@ hipError_t PICHA_CAT(launch_edges_pixel, PICHA_RUN_PIXEL)(const RunParams &p, hi
     [[maybe_unused]] constexpr bool S16 = pixel_is16(PICHA_RUN_PIXEL);
     if (!p.stash && !p.edge_image) return hipSuccess;
     [[maybe_unused]] dim3 grid((p.dst_h + p.edge_rows - 1) / p.edge_rows, 2, p.n_images);
-    [[maybe_unused]] const size_t lds = sizeof(float) * kEdgeFloats;
+    [[maybe_unused]] const size_t lds = sizeof(float) * (p.edge_lds_floats > 0 && p.edge_lds_floats <= kEdgeFloats ? std::min(kEdgeFloats, (p.edge_lds_floats + 127) / 64 * 64) : kEdgeFloats);
     [[maybe_unused]] const int txe = (p.x_taps + 3) / 4 * 4;
     if (p.cv_on) {
         if (!p.edge_image) return hipErrorInvalidValue;

@@ -10,6 +10,8 @@ import ctypes
 import re
 
 import numpy as np
+import os
+
 import pytest
 
 import picha_amd as picha
@@ -688,6 +690,74 @@ def test_run_kernel_shared_unpack_matches_oracle(case):
     finally:
         for k in keys:
             N.check(N.lib().picha_hip_set_option(k, 0))
+
+
+@pytest.mark.parametrize("case", [("grey", (3840, 300), (512, 40), "lanczos"), ("greya", (960, 130), (128, 31), "lanczos"), ("rgb", (1920, 135), (256, 18), None),
+                                  ("rgba", (1920, 216), (960, 108), "lanczos"), ("r16g16b16a16", (1920, 64), (480, 16), "mitchel")], ids=lambda c: "%s-%dx%d-%s" % (c[0], c[1][0], c[1][1], c[3]))
+def test_edge_kernel_block_rows_match_oracle(case):
+    """r05, third session: edge_rows caps the output rows per block of resize_edges_kernel (more, shorter waves; the block's LDS is sized for what it holds, not 8 KB):
+    every cap gives the oracle's bytes."""
+    pixel, (sw, sh), (dw, dh), filt = case
+    rng = np.random.default_rng(sw + dh)
+    img = rand_image(rng, sw, sh, pixel, pad=4, edge_values=True)
+    opts = {"width": dw, "height": dh}
+    if filt:
+        opts["filter"] = filt
+    want = oracle_resize(img, dw, dh, filt or "cubic", 1.0 if filt else 0.70)
+    try:
+        for er in (0, 1, 5, 16, 33, 64):
+            N.check(N.lib().picha_hip_set_option(b"edge_rows", er))
+            for chunks in (0, 3):
+                N.check(N.lib().picha_hip_set_option(b"row_chunks", chunks))
+                got = picha.resizeSync(img, opts)
+                assert max_code_diff(got, want) == 0, (case, er, chunks, N.lib().picha_hip_last_kernel())
+    finally:
+        N.check(N.lib().picha_hip_set_option(b"edge_rows", 0))
+        N.check(N.lib().picha_hip_set_option(b"row_chunks", 0))
+
+
+# (collected only for a -DPICHA_RUN_EFUSE measurement build: PICHA_TEST_EFUSE=1 PICHA_HIP_LIB=<that build>; green in scripts/sessions/r05_call50.sh)
+def _edge_blocks_inside_the_grid_match_oracle(geom):
+    """r05, third session: run_efuse = 1 — cfg3b's shape (grey 7.5x, 30 taps, shared unpack) carries the edge pass as two more workgroups per (row chunk, image) of
+    the march's own plain grid (",edgeblocks" in the name, no resize_edges launch); the march's side lanes store only the columns that are not clipped, so the
+    two writers never touch the same byte.  Bit-exact against the oracle over row chunkings, workgroup widths, strides and sub-views (fma: <= 1); forms that cannot carry
+    the blocks (item lists, one-wave workgroups) fall back to the edge kernel."""
+    (sw, sh), (dw, dh) = geom
+    rng = np.random.default_rng(sw * 7 + dh)
+    big = rand_image(rng, sw + 8, sh + 3, "grey", pad=int(rng.choice([0, 4, 12])), edge_values=True)
+    keys = (b"run", b"run_shu", b"run_efuse", b"row_chunks", b"work", b"block_waves", b"numerics")
+    opts = {"width": dw, "height": dh, "filter": "lanczos"}
+    try:
+        for k, v in ((b"run", 1), (b"run_shu", 1), (b"run_efuse", 1)):
+            N.check(N.lib().picha_hip_set_option(k, v))
+        picha.resizeSync(big.subView(0, 0, sw, sh), opts)
+        if ",edgeblocks" not in N.lib().picha_hip_last_kernel().decode():
+            pytest.skip("the in-grid edge blocks are a measurement build (-DPICHA_RUN_EFUSE): slower than the edge kernel in the reference flavour, profiles/r05_ab_edge_blocks.txt")
+        for img in (big.subView(0, 0, sw, sh), big.subView(5, 1, sw, sh)):
+            want = oracle_resize(img, dw, dh, "lanczos", 1.0)
+            for chunks, work, bw in ((0, 0, 0), (1, 0, 2), (3, 0, 4), (7, 0, 2), (2, 1, 2), (2, 0, 1)):
+                for k, v in ((b"row_chunks", chunks), (b"work", work), (b"block_waves", bw)):
+                    N.check(N.lib().picha_hip_set_option(k, v))
+                for numerics, tol in ((0, 0), (1, 1)):
+                    N.check(N.lib().picha_hip_set_option(b"numerics", numerics))
+                    got = picha.resizeSync(img, opts)
+                    name = N.lib().picha_hip_last_kernel().decode()
+                    assert name.startswith("resize_run<ch1,u8,Q2,PX15,TX30,P4") and ",shu" in name, name
+                    if work == 0 and bw != 1:
+                        assert ",edgeblocks" in name and "resize_edges" not in name, name
+                    else:
+                        assert "+ resize_edges<" in name, name
+                    assert max_code_diff(got, want) <= tol, (geom, chunks, work, bw, numerics, name)
+                N.check(N.lib().picha_hip_set_option(b"numerics", 0))
+    finally:
+        for k in keys:
+            N.check(N.lib().picha_hip_set_option(k, 0))
+
+
+if os.environ.get("PICHA_TEST_EFUSE"):
+    test_run_kernel_edge_blocks_inside_the_grid_match_oracle = pytest.mark.gpu(pytest.mark.parametrize(
+        "geom", [((3840, 300), (512, 40)), ((3840, 2160), (512, 512)), ((1935, 158), (258, 21)), ((7680, 127), (1024, 17))],
+        ids=lambda g: "%dx%d-%dx%d" % (g[0] + g[1]))(_edge_blocks_inside_the_grid_match_oracle))
 
 
 @pytest.mark.parametrize("edges", [1, 2, 3])
