@@ -2124,7 +2124,13 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             // residency already takes two rounds; measured optima move by format): the chunk rule above stays.
             const int resident = acc_kernel_resident_blocks(pixel, p);
             const long long row_blocks = (long long)n * ((col_waves * 64 + p.long_block - 1) / p.long_block);
-            const double cap = (p.long_block == 256 ? 1.0 : 0.8) * resident;
+            // (r05, third session; profiles/r05_ab_acc_long_chunks.txt) one- and two-byte pixels: the time falls with the chunk count up to ONE FREE SLOT PER CU and jumps by 30-50 %
+            // at the queried residency itself (64 x 4K grey -> 384x216, 48 taps: 6 chunks 0.433 ms, 8 chunks = 12 of 13 slots 0.349, 9 chunks 0.513; greya -> 333x187 -17 %); and a
+            // launch of several ragged rounds is slower than one round of longer chunks (256 images: 6 chunks = 2.8 rounds 1.52 ms, 2 chunks = one round 1.27)
+            const bool narrow = kBytes[pixel] <= 2 && p.long_block == 64;
+            int cus = 0, dev_id = 0;
+            if (narrow && (hipGetDevice(&dev_id) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev_id) != hipSuccess)) cus = 0;
+            const double cap = narrow && cus > 0 && resident >= 6 * cus ? (double)(resident - cus) : (p.long_block == 256 ? 1.0 : 0.8) * resident;
             for (int c = d0.height; resident > 0 && c > p.n_chunks; --c) {
                 const int rows = (d0.height + c - 1) / c, nc = (d0.height + rows - 1) / rows;
                 if (row_blocks * nc > cap) continue;
@@ -2133,7 +2139,7 @@ int resize_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst,
             }
             // ... and a launch of one to two such rounds is cut back to one: its second round would be partly idle
             // (31 x 24 Mpixel rgba -> 300x200 lanczos: 12 chunks 3.03 ms, 11 chunks 1.80)
-            if (resident > 0 && row_blocks * p.n_chunks > cap && row_blocks * p.n_chunks <= 2.0 * cap) {
+            if (resident > 0 && row_blocks * p.n_chunks > cap && (row_blocks * p.n_chunks <= 2.0 * cap || (narrow && row_blocks * 2 <= cap))) {
                 for (int c = p.n_chunks - 1; c >= 1; --c) {
                     const int rows = (d0.height + c - 1) / c, nc = (d0.height + rows - 1) / rows;
                     if (row_blocks * nc > cap) continue;
