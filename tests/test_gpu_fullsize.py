@@ -280,3 +280,27 @@ def test_cfg3_full_size_chained_call_equals_the_two_calls():
     torch.cuda.synchronize()
     assert all(other.equal_pixels(ref))
     assert not all(other.equal_pixels(one))   # the two orders are different operations
+
+
+@pytest.mark.parametrize("n,pixel,dw,dh,filt", [(64, "grey", 384, 216, "cubic"), (256, "grey", 384, 216, "cubic"), (128, "greya", 333, 187, "mitchel")],
+                         ids=lambda v: str(v))
+def test_long_window_thumbnails_at_the_planners_chunking_match_other_chunkings_and_oracle(n, pixel, dw, dh, filt):
+    """r05, third session: 4K -> thumbnails at >= 10x with explicit filters (48-tap windows) run on resize_acc_long, whose chunk count for one- and two-byte
+    pixels now fills the queried residency up to one free workgroup slot per CU, or cuts a launch of several rounds back to one round of long chunks
+    (256 images: two chunks of 108 rows).  Full batches at the planner's own chunking against forced chunkings (same bytes whatever the chunking) and
+    the oracle on the first and last image."""
+    src = DeviceBatch(n, 3840, 2160, pixel).fill_random(11)
+    sums = {}
+    for chunks in (0, 6, 1, 27):
+        set_opt("row_chunks", chunks)
+        out = resize_batch(src, dw, dh, filter=filt)
+        torch.cuda.synchronize()
+        name = N.lib().picha_hip_last_kernel().decode()
+        assert name.startswith("resize_acc_long<ch%d,u8,TX48" % N.PIXEL_CHANNELS[pixel]), name
+        sums[chunks] = digest(out)
+        if chunks == 0:
+            planner = out
+    assert len(set(sums.values())) == 1, sums
+    for i in (0, n - 1):
+        exp = oracle_resize(src.image_host(i), dw, dh, filt, 1.0)
+        assert np.array_equal(planner.image_host(i).pixels(), exp.pixels()), i
