@@ -1166,7 +1166,9 @@ int run_group(DeviceCtx *ctx, const picha_image *src, const picha_image *dst, in
     // (r05: greya at 7.5x / 21 taps, a tie with the accumulator kernel in its plain form, wins in the shared-unpack form: 128 x 4K -> 512x288 0.579 -> 0.529 ms)
     const bool greya_shu21 = ch == 2 && period_px == 15 && !fma && !ring_mode && opt_run_shu != 2 && opt_run_ws != 2 && opt_run_edges != 1 && n >= 96 &&
                              run_kernel_supported(pixel, period, period_px, ktaps, per_lane, nacc, ceil_off, -2, std::min(2, period));
-    const bool short_ok = shu_only ? wave_cols * s0.height >= 200000 : period_px == 15 ? ((ch == 1 && n >= 192) || greya_shu21) : (ch <= 2 && n >= 96);
+    const bool short_ok = shu_only ? wave_cols * s0.height >= 200000 : period_px == 15 ? ((ch == 1 && n >= 192) || greya_shu21) : (ch <= 2 && (n >= 96 || wave_cols * s0.height >= 400000));
+    // (r05, third session: the count of IMAGES says little about 4K sources — 64 x 4K grey -> 2560x1440 -27 %, -> 1536x864 -28 %, -> 1280x720 -6.5 %, greya 1.5x -1 % against the
+    // accumulator kernel the n >= 96 rule left them on; >= 400 000 wave-rows as well: profiles/r05_ab_planner_declines.txt)
     if (!ring_mode && xhl < 0 && opt_run == 0 && ktaps < 26 && !short_ok) RUN_GROUP_NA;
     if (ylist && opt_run == 0 && wave_cols * s0.height < 200000) RUN_GROUP_NA;   // (the row-list shapes were measured on batches: lanczos thumbnails of 64-128 4K images)
     // one phase's weights in SGPRs (r04): where instantiated — the 7.5x shapes, whose 2 x 30 lane-uniform weight registers held the
